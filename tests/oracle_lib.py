@@ -1,0 +1,192 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so) -- test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
+_u64p = C.POINTER(C.c_uint64)
+_u32p = C.POINTER(C.c_uint32)
+
+
+class OrcCSR(C.Structure):
+    _fields_ = [("n_rows", C.c_uint32), ("row_ptr", _u32p), ("col", _u32p), ("coeff", _u64p)]
+
+
+class OrcR1CS(C.Structure):
+    _fields_ = [("nC", C.c_uint32), ("nIn", C.c_uint32), ("V", C.c_uint32),
+                ("A", OrcCSR), ("B", OrcCSR), ("C", OrcCSR)]
+
+
+class OrcProof(C.Structure):
+    _fields_ = [(n, C.c_uint64 * 4) for n in
+                ("a_x", "a_y", "b_x_c0", "b_x_c1", "b_y_c0", "b_y_c1", "c_x", "c_y")] + \
+               [("a_inf", C.c_uint32), ("b_inf", C.c_uint32), ("c_inf", C.c_uint32), ("_pad", C.c_uint32)]
+
+
+def _p64(a):
+    return a.ctypes.data_as(_u64p)
+
+
+def _p32(a):
+    return a.ctypes.data_as(_u32p)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        so = os.path.join(ORACLE_DIR, "liboracle.so")
+        if not os.path.exists(so):
+            subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+        L = C.CDLL(so)
+        L.orc_proof_to_json.restype = C.c_size_t
+        L.orc_vk_to_json.restype = C.c_size_t
+        L.orc_pk_ptr.restype = C.c_void_p
+        L.orc_domain_size.restype = C.c_uint32
+        _lib = L
+    return _lib
+
+
+class Keep:
+    """holds numpy arrays alive next to the ctypes struct that points into them"""
+    def __init__(self, struct, refs):
+        self.struct, self.refs = struct, refs
+
+
+def r1cs_struct(r):
+    refs = []
+    def csr(m):
+        rp = np.ascontiguousarray(m.row_ptr, dtype=np.uint32)
+        co = np.ascontiguousarray(m.col, dtype=np.uint32)
+        cf = np.ascontiguousarray(m.coeff, dtype=np.uint64)
+        refs.extend([rp, co, cf])
+        return OrcCSR(m.n_rows, _p32(rp), _p32(co), _p64(cf))
+    s = OrcR1CS(r.nC, r.nIn, r.V, csr(r.A), csr(r.B), csr(r.C))
+    return Keep(s, refs)
+
+
+def ntt(a, logm, inverse=False, coset=False):
+    out = np.ascontiguousarray(a, dtype=np.uint64).copy()
+    lib().orc_ntt(_p64(out), C.c_uint32(logm), int(inverse), int(coset))
+    return out
+
+
+def witness_map(r, w_mont):
+    k = r1cs_struct(r)
+    m = r.domain_size
+    h = np.zeros((m + 1, 4), dtype=np.uint64)
+    w = np.ascontiguousarray(w_mont, dtype=np.uint64)
+    rc = lib().orc_witness_map(C.byref(k.struct), _p64(w), _p64(h))
+    assert rc == 0
+    return h
+
+
+def msm(bases, scalars, g2=False, c=0, naive=False):
+    bases = np.ascontiguousarray(bases, dtype=np.uint64)
+    scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
+    n = scalars.shape[0]
+    out = np.zeros(16 if g2 else 8, dtype=np.uint64)
+    L = lib()
+    if naive:
+        (L.orc_msm_g2_naive if g2 else L.orc_msm_g1_naive)(_p64(bases), _p64(scalars), C.c_size_t(n), _p64(out))
+    else:
+        (L.orc_msm_g2 if g2 else L.orc_msm_g1)(_p64(bases), _p64(scalars), C.c_size_t(n), C.c_uint(c), _p64(out))
+    return out
+
+
+def batch_mul(scalars, g2=False):
+    scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
+    n = scalars.shape[0]
+    out = np.zeros((n, 16 if g2 else 8), dtype=np.uint64)
+    (lib().orc_batch_mul_g2 if g2 else lib().orc_batch_mul_g1)(_p64(scalars), C.c_size_t(n), _p64(out))
+    return out
+
+
+class PK:
+    """orc_pk handle + numpy views of its parts"""
+    def __init__(self, handle):
+        self.h = handle
+        s = (C.c_uint32 * 6)()
+        lib().orc_pk_sizes(handle, s)
+        self.a_domain, self.nA, self.b_domain, self.nB, self.nH, self.nL = list(s)
+
+    def part(self, which, shape, dtype=np.uint64):
+        p = lib().orc_pk_ptr(self.h, which)
+        n = int(np.prod(shape))
+        if n == 0:
+            return np.zeros(shape, dtype=dtype)
+        ct = (C.c_uint64 if dtype == np.uint64 else C.c_uint32) * n
+        return np.frombuffer(ct.from_address(p), dtype=dtype).reshape(shape).copy()
+
+    def parts(self):
+        return dict(
+            alpha_g1=self.part(0, (8,)), beta_g1=self.part(1, (8,)), beta_g2=self.part(2, (16,)),
+            delta_g1=self.part(3, (8,)), delta_g2=self.part(4, (16,)),
+            a_domain=self.a_domain, a_idx=self.part(5, (self.nA,), np.uint32), a_val=self.part(6, (self.nA, 8)),
+            b_domain=self.b_domain, b_idx=self.part(7, (self.nB,), np.uint32), b_val=self.part(8, (self.nB, 16)),
+            H=self.part(9, (self.nH, 8)), L=self.part(10, (self.nL, 8)))
+
+    def write_raw(self, path):
+        assert lib().orc_pk_write_raw(self.h, path.encode()) == 0
+
+    def __del__(self):
+        try:
+            lib().orc_pk_free(self.h)
+        except Exception:
+            pass
+
+
+class VK:
+    def __init__(self, handle):
+        self.h = handle
+
+    def to_json(self):
+        buf = C.create_string_buffer(1 << 20)
+        n = lib().orc_vk_to_json(self.h, buf, C.c_size_t(len(buf)))
+        return buf.raw[:n].decode()
+
+    def __del__(self):
+        try:
+            lib().orc_vk_free(self.h)
+        except Exception:
+            pass
+
+
+def keygen(r, seed=None, toxic=None):
+    k = r1cs_struct(r)
+    pk, vk = C.c_void_p(), C.c_void_p()
+    if toxic is not None:
+        from ethsnarks_amd.fields import ints_to_limbs
+        t = np.ascontiguousarray(ints_to_limbs(toxic)).reshape(-1)
+        rc = lib().orc_keygen_explicit(C.byref(k.struct), _p64(t), C.byref(pk), C.byref(vk))
+    else:
+        rc = lib().orc_keygen(C.byref(k.struct), C.c_uint64(seed), C.byref(pk), C.byref(vk))
+    assert rc == 0
+    return PK(pk), VK(vk)
+
+
+def read_raw(path):
+    pk = C.c_void_p()
+    rc = lib().orc_pk_read_raw(path.encode(), C.byref(pk))
+    if rc != 0:
+        raise IOError("orc_pk_read_raw failed: %d" % rc)
+    return PK(pk)
+
+
+def prove(pk, r, w_mont, c=0):
+    """returns (proof_json, phase_seconds[6])"""
+    k = r1cs_struct(r)
+    w = np.ascontiguousarray(w_mont, dtype=np.uint64)
+    proof = OrcProof()
+    ph = (C.c_double * 6)()
+    rc = lib().orc_prove(pk.h, C.byref(k.struct), _p64(w), C.c_uint(c), C.byref(proof), ph)
+    if rc != 0:
+        raise RuntimeError("orc_prove failed: %d" % rc)
+    buf = C.create_string_buffer(4096 + 80 * r.nIn)
+    inputs = np.ascontiguousarray(w[1:1 + r.nIn])
+    n = lib().orc_proof_to_json(C.byref(proof), _p64(inputs) if r.nIn else None, C.c_uint32(r.nIn), buf, C.c_size_t(len(buf)))
+    return buf.raw[:n].decode(), list(ph)
