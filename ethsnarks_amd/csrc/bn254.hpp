@@ -1,0 +1,299 @@
+// bn254.hpp -- alt_bn128 field and curve arithmetic for the HIP backend (gfx950) and its host side.
+//
+// This is the from-scratch device equivalent of what the reference gets from libff
+// (depends/libsnark/depends/libff [ABSENT in the checkout]): Fr, Fq, Fq2, G1, G2.  Used by
+//   r1cs_gg_ppzksnark_zok_prover  (src/r1cs_gg_ppzksnark_zok/r1cs_gg_ppzksnark_zok.tcc:451-550).
+//
+// Representation: 8 x u32 little-endian limbs, Montgomery form with R = 2^256 -- bit-for-bit the
+// 4 x u64 libff::Fp_model<4> memory image, so `pb.values` and the `.raw` key need no conversion.
+// 32-bit limbs because the CDNA4 VALU multiplies 32x32 (v_mad_u64_u32 / v_mul_hi_u32); everything is
+// fully unrolled so a field element lives in 8 VGPRs.  No MFMA: there is no dense contraction here.
+//
+// Curve points: affine {x, y} with (0,0) = infinity (neither curve contains it); accumulators use
+// extended Jacobian "XYZZ" coordinates (x = X/ZZ, y = Y/ZZZ; ZZ = 0 is infinity): mixed addition is
+// 8M + 2S with no inversion, which is what bucket accumulation wants.
+#pragma once
+#include <stdint.h>
+
+#ifndef ZK_HD
+#define ZK_HD __host__ __device__ __forceinline__
+#endif
+
+namespace zk {
+
+struct alignas(16) fe { uint32_t l[8]; };
+
+struct FrParams {
+    static ZK_HD constexpr uint32_t p(int i) {
+        constexpr uint32_t v[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+        return v[i];
+    }
+    static ZK_HD constexpr uint32_t one(int i) {   // R mod r
+        constexpr uint32_t v[8] = {0x4ffffffbu, 0xac96341cu, 0x9f60cd29u, 0x36fc7695u, 0x7879462eu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
+        return v[i];
+    }
+    static ZK_HD constexpr uint32_t r2(int i) {    // R^2 mod r
+        constexpr uint32_t v[8] = {0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u, 0x53bb8085u, 0x8c49833du, 0x7f4e44a5u, 0x0216d0b1u};
+        return v[i];
+    }
+    static constexpr uint32_t inv = 0xefffffffu;   // -r^-1 mod 2^32
+};
+struct FqParams {
+    static ZK_HD constexpr uint32_t p(int i) {
+        constexpr uint32_t v[8] = {0xd87cfd47u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+        return v[i];
+    }
+    static ZK_HD constexpr uint32_t one(int i) {   // R mod q
+        constexpr uint32_t v[8] = {0xc58f0d9du, 0xd35d438du, 0xf5c70b3du, 0x0a78eb28u, 0x7879462cu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
+        return v[i];
+    }
+    static ZK_HD constexpr uint32_t r2(int i) {    // R^2 mod q
+        constexpr uint32_t v[8] = {0x538afa89u, 0xf32cfc5bu, 0xd44501fbu, 0xb5e71911u, 0x0a417ff6u, 0x47ab1effu, 0xcab8351fu, 0x06d89f71u};
+        return v[i];
+    }
+    static constexpr uint32_t inv = 0xe4866389u;   // -q^-1 mod 2^32
+};
+
+// ------------------------------------------------------------------------------------------------
+// prime field, fully reduced representatives in [0, p)
+template <class P>
+struct Field {
+    typedef fe elem;
+
+    static ZK_HD fe zero() { fe r; for (int i = 0; i < 8; i++) r.l[i] = 0; return r; }
+    static ZK_HD fe one() { fe r; for (int i = 0; i < 8; i++) r.l[i] = P::one(i); return r; }
+    static ZK_HD bool is_zero(const fe &a) {
+        uint32_t t = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) t |= a.l[i];
+        return t == 0;
+    }
+    static ZK_HD bool eq(const fe &a, const fe &b) {
+        uint32_t t = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) t |= a.l[i] ^ b.l[i];
+        return t == 0;
+    }
+    // r = a - p if a >= p else a   (a < 2p)
+    static ZK_HD fe reduce_once(const fe &a) {
+        fe d; uint64_t br = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            uint64_t t = (uint64_t)a.l[i] - P::p(i) - br;
+            d.l[i] = (uint32_t)t; br = (t >> 32) & 1;
+        }
+        fe r;
+#pragma unroll
+        for (int i = 0; i < 8; i++) r.l[i] = br ? a.l[i] : d.l[i];
+        return r;
+    }
+    static ZK_HD fe add(const fe &a, const fe &b) {
+        fe s; uint64_t c = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { c += (uint64_t)a.l[i] + b.l[i]; s.l[i] = (uint32_t)c; c >>= 32; }
+        return reduce_once(s);     // p < 2^254 so a + b < 2^255: no carry out of limb 7
+    }
+    static ZK_HD fe sub(const fe &a, const fe &b) {
+        fe d; uint64_t br = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            uint64_t t = (uint64_t)a.l[i] - b.l[i] - br;
+            d.l[i] = (uint32_t)t; br = (t >> 32) & 1;
+        }
+        uint32_t mask = br ? 0xffffffffu : 0u;
+        uint64_t c = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { c += (uint64_t)d.l[i] + (P::p(i) & mask); d.l[i] = (uint32_t)c; c >>= 32; }
+        return d;
+    }
+    static ZK_HD fe neg(const fe &a) { return is_zero(a) ? a : sub(zero(), a); }
+    static ZK_HD fe dbl(const fe &a) { return add(a, a); }
+
+    // Montgomery product a*b*R^-1 mod p (CIOS over 32-bit limbs; each step is one v_mad_u64_u32)
+    static ZK_HD fe mul(const fe &a, const fe &b) {
+        uint32_t t[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++) t[i] = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            uint64_t c = 0;
+            const uint32_t bi = b.l[i];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                c = (uint64_t)a.l[j] * bi + t[j] + c;
+                t[j] = (uint32_t)c; c >>= 32;
+            }
+            c += t[8];
+            t[8] = (uint32_t)c;                       // t < 2^288 throughout: no 10th limb (p < 2^254)
+            const uint32_t m = t[0] * P::inv;
+            c = (uint64_t)m * P::p(0) + t[0];
+            c >>= 32;
+#pragma unroll
+            for (int j = 1; j < 8; j++) {
+                c = (uint64_t)m * P::p(j) + t[j] + c;
+                t[j - 1] = (uint32_t)c; c >>= 32;
+            }
+            c += t[8];
+            t[7] = (uint32_t)c; t[8] = (uint32_t)(c >> 32);
+        }
+        fe r;
+#pragma unroll
+        for (int i = 0; i < 8; i++) r.l[i] = t[i];
+        return reduce_once(r);                        // result < 2p < 2^255, t[8] == 0
+    }
+    static ZK_HD fe sqr(const fe &a) { return mul(a, a); }
+
+    static ZK_HD fe to_mont(const fe &a) { fe r2; for (int i = 0; i < 8; i++) r2.l[i] = P::r2(i); return mul(a, r2); }
+    static ZK_HD fe from_mont(const fe &a) { fe o = zero(); o.l[0] = 1; return mul(a, o); }
+
+    static ZK_HD fe pow(const fe &a, const uint32_t e[8]) {
+        fe acc = one(), base = a;
+        for (int i = 0; i < 256; i++) {
+            if ((e[i >> 5] >> (i & 31)) & 1) acc = mul(acc, base);
+            base = sqr(base);
+        }
+        return acc;
+    }
+    static ZK_HD fe pow_u64(const fe &a, uint64_t e) {
+        fe acc = one(), base = a;
+        while (e) { if (e & 1) acc = mul(acc, base); base = sqr(base); e >>= 1; }
+        return acc;
+    }
+    static ZK_HD fe inv(const fe &a) {                // Fermat a^(p-2); host-side and rare device use only
+        uint32_t e[8];
+        for (int i = 0; i < 8; i++) e[i] = P::p(i);
+        e[0] -= 2;                                    // p(0) >= 2 for both moduli, no borrow
+        return pow(a, e);
+    }
+    static ZK_HD fe from_u64(uint64_t v) { fe t = zero(); t.l[0] = (uint32_t)v; t.l[1] = (uint32_t)(v >> 32); return to_mont(t); }
+};
+
+typedef Field<FrParams> Fr;
+typedef Field<FqParams> Fq;
+
+// ------------------------------------------------------------------------------------------------
+// Fq2 = Fq[u]/(u^2 + 1)
+struct alignas(16) fe2 { fe c0, c1; };
+
+struct Fq2 {
+    typedef fe2 elem;
+    static ZK_HD fe2 zero() { fe2 r; r.c0 = Fq::zero(); r.c1 = Fq::zero(); return r; }
+    static ZK_HD fe2 one() { fe2 r; r.c0 = Fq::one(); r.c1 = Fq::zero(); return r; }
+    static ZK_HD bool is_zero(const fe2 &a) { return Fq::is_zero(a.c0) && Fq::is_zero(a.c1); }
+    static ZK_HD bool eq(const fe2 &a, const fe2 &b) { return Fq::eq(a.c0, b.c0) && Fq::eq(a.c1, b.c1); }
+    static ZK_HD fe2 add(const fe2 &a, const fe2 &b) { fe2 r; r.c0 = Fq::add(a.c0, b.c0); r.c1 = Fq::add(a.c1, b.c1); return r; }
+    static ZK_HD fe2 sub(const fe2 &a, const fe2 &b) { fe2 r; r.c0 = Fq::sub(a.c0, b.c0); r.c1 = Fq::sub(a.c1, b.c1); return r; }
+    static ZK_HD fe2 neg(const fe2 &a) { fe2 r; r.c0 = Fq::neg(a.c0); r.c1 = Fq::neg(a.c1); return r; }
+    static ZK_HD fe2 dbl(const fe2 &a) { return add(a, a); }
+    static ZK_HD fe2 mul(const fe2 &a, const fe2 &b) {       // Karatsuba: 3 Fq products
+        fe v0 = Fq::mul(a.c0, b.c0), v1 = Fq::mul(a.c1, b.c1);
+        fe s = Fq::mul(Fq::add(a.c0, a.c1), Fq::add(b.c0, b.c1));
+        fe2 r; r.c0 = Fq::sub(v0, v1); r.c1 = Fq::sub(Fq::sub(s, v0), v1); return r;
+    }
+    static ZK_HD fe2 sqr(const fe2 &a) {                      // complex squaring: 2 Fq products
+        fe p = Fq::mul(a.c0, a.c1);
+        fe2 r; r.c0 = Fq::mul(Fq::add(a.c0, a.c1), Fq::sub(a.c0, a.c1)); r.c1 = Fq::add(p, p); return r;
+    }
+    static ZK_HD fe2 inv(const fe2 &a) {
+        fe n = Fq::inv(Fq::add(Fq::sqr(a.c0), Fq::sqr(a.c1)));
+        fe2 r; r.c0 = Fq::mul(a.c0, n); r.c1 = Fq::neg(Fq::mul(a.c1, n)); return r;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// short Weierstrass y^2 = x^3 + b, a = 0, over F (Fq for G1, Fq2 for G2); formulas never use b.
+template <class F>
+struct Curve {
+    typedef typename F::elem E;
+    struct alignas(16) Affine { E x, y; };
+    struct alignas(16) XYZZ { E X, Y, ZZ, ZZZ; };
+
+    static ZK_HD bool is_inf(const Affine &p) { return F::is_zero(p.x) && F::is_zero(p.y); }
+    static ZK_HD bool is_inf(const XYZZ &p) { return F::is_zero(p.ZZ); }
+    static ZK_HD XYZZ infinity() { XYZZ r; r.X = F::zero(); r.Y = F::zero(); r.ZZ = F::zero(); r.ZZZ = F::zero(); return r; }
+    static ZK_HD Affine aff_infinity() { Affine r; r.x = F::zero(); r.y = F::zero(); return r; }
+    static ZK_HD XYZZ from_affine(const Affine &p) {
+        if (is_inf(p)) return infinity();
+        XYZZ r; r.X = p.x; r.Y = p.y; r.ZZ = F::one(); r.ZZZ = F::one(); return r;
+    }
+    static ZK_HD Affine neg(const Affine &p) { Affine r; r.x = p.x; r.y = F::neg(p.y); return r; }
+    static ZK_HD XYZZ neg(const XYZZ &p) { XYZZ r = p; r.Y = F::neg(p.Y); return r; }
+
+    // 2 * affine (mdbl-2008-s-1)
+    static ZK_HD XYZZ dbl_affine(const Affine &p) {
+        if (is_inf(p)) return infinity();
+        E U = F::dbl(p.y), V = F::sqr(U), W = F::mul(U, V), S = F::mul(p.x, V);
+        E xx = F::sqr(p.x), M = F::add(F::dbl(xx), xx);
+        XYZZ r;
+        r.X = F::sub(F::sqr(M), F::dbl(S));
+        r.Y = F::sub(F::mul(M, F::sub(S, r.X)), F::mul(W, p.y));
+        r.ZZ = V; r.ZZZ = W;
+        return r;
+    }
+    // dbl-2008-s-1
+    static ZK_HD XYZZ dbl(const XYZZ &p) {
+        if (is_inf(p)) return p;
+        E U = F::dbl(p.Y), V = F::sqr(U), W = F::mul(U, V), S = F::mul(p.X, V);
+        E xx = F::sqr(p.X), M = F::add(F::dbl(xx), xx);
+        XYZZ r;
+        r.X = F::sub(F::sqr(M), F::dbl(S));
+        r.Y = F::sub(F::mul(M, F::sub(S, r.X)), F::mul(W, p.Y));
+        r.ZZ = F::mul(V, p.ZZ); r.ZZZ = F::mul(W, p.ZZZ);
+        return r;
+    }
+    // p + q, q affine (madd-2008-s); all exceptional cases handled -- bit-exactness needs them
+    static ZK_HD XYZZ madd(const XYZZ &p, const Affine &q) {
+        if (is_inf(q)) return p;
+        if (is_inf(p)) { XYZZ r; r.X = q.x; r.Y = q.y; r.ZZ = F::one(); r.ZZZ = F::one(); return r; }
+        E U2 = F::mul(q.x, p.ZZ), S2 = F::mul(q.y, p.ZZZ);
+        E Pd = F::sub(U2, p.X), R = F::sub(S2, p.Y);
+        if (F::is_zero(Pd)) {
+            if (F::is_zero(R)) return dbl_affine(q);
+            return infinity();
+        }
+        E PP = F::sqr(Pd), PPP = F::mul(Pd, PP), Q = F::mul(p.X, PP);
+        XYZZ r;
+        r.X = F::sub(F::sub(F::sqr(R), PPP), F::dbl(Q));
+        r.Y = F::sub(F::mul(R, F::sub(Q, r.X)), F::mul(p.Y, PPP));
+        r.ZZ = F::mul(p.ZZ, PP); r.ZZZ = F::mul(p.ZZZ, PPP);
+        return r;
+    }
+    // p + q (add-2008-s)
+    static ZK_HD XYZZ add(const XYZZ &p, const XYZZ &q) {
+        if (is_inf(p)) return q;
+        if (is_inf(q)) return p;
+        E U1 = F::mul(p.X, q.ZZ), U2 = F::mul(q.X, p.ZZ);
+        E S1 = F::mul(p.Y, q.ZZZ), S2 = F::mul(q.Y, p.ZZZ);
+        E Pd = F::sub(U2, U1), R = F::sub(S2, S1);
+        if (F::is_zero(Pd)) {
+            if (F::is_zero(R)) return dbl(p);
+            return infinity();
+        }
+        E PP = F::sqr(Pd), PPP = F::mul(Pd, PP), Q = F::mul(U1, PP);
+        XYZZ r;
+        r.X = F::sub(F::sub(F::sqr(R), PPP), F::dbl(Q));
+        r.Y = F::sub(F::mul(R, F::sub(Q, r.X)), F::mul(S1, PPP));
+        r.ZZ = F::mul(F::mul(p.ZZ, q.ZZ), PP); r.ZZZ = F::mul(F::mul(p.ZZZ, q.ZZZ), PPP);
+        return r;
+    }
+    // k * p for a small non-negative integer k (bucket-offset weighting), MSB-first double-and-add
+    static ZK_HD XYZZ mul_small(const XYZZ &p, uint32_t k) {
+        XYZZ acc = infinity();
+        for (int i = 31; i >= 0; i--) {
+            acc = dbl(acc);
+            if ((k >> i) & 1) acc = add(acc, p);
+        }
+        return acc;
+    }
+    static ZK_HD Affine to_affine(const XYZZ &p) {      // one inversion: 1/(ZZ*ZZZ)
+        if (is_inf(p)) return aff_infinity();
+        E i = F::inv(F::mul(p.ZZ, p.ZZZ));
+        E izz = F::mul(i, p.ZZZ), izzz = F::mul(i, p.ZZ);
+        Affine r; r.x = F::mul(p.X, izz); r.y = F::mul(p.Y, izzz); return r;
+    }
+};
+
+typedef Curve<Fq> G1;
+typedef Curve<Fq2> G2;
+
+}  // namespace zk

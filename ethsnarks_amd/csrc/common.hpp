@@ -1,0 +1,37 @@
+// common.hpp -- runtime include, launch macros and error plumbing for the HIP backend.
+#pragma once
+#ifdef ZK_EMUL
+#include "hip_emul.h"   // tests/emul: CPU stand-in used only by the not-gpu test suite
+#define ZK_LAUNCH(kern, grid, block, stream, ...) \
+    zk_emul::launch(false, dim3(grid), dim3(block), [&] { kern(__VA_ARGS__); })
+#define ZK_LAUNCH_SYNC(kern, grid, block, stream, ...) \
+    zk_emul::launch(true, dim3(grid), dim3(block), [&] { kern(__VA_ARGS__); })
+#else
+#include <hip/hip_runtime.h>
+#define ZK_LAUNCH(kern, grid, block, stream, ...) \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, stream, __VA_ARGS__)
+#define ZK_LAUNCH_SYNC ZK_LAUNCH
+#endif
+#define ZK_HD __host__ __device__ __forceinline__
+#define ZK_D __device__ __forceinline__
+
+#include <stdint.h>
+#include <stdio.h>
+
+// error codes of the C ABI (include/zkhip.h)
+enum {
+    ZK_OK = 0, ZK_ERR_ARG = 1, ZK_ERR_IO = 2, ZK_ERR_FORMAT = 3, ZK_ERR_HIP = 4, ZK_ERR_NOMEM = 5,
+    ZK_ERR_SHAPE = 6, ZK_ERR_DEGREE = 7, ZK_ERR_NODEVICE = 8, ZK_ERR_BUFFER = 9
+};
+
+namespace zk {
+extern thread_local char g_last_error[256];
+inline int hip_fail(hipError_t e, const char *what, const char *file, int line) {
+    snprintf(g_last_error, sizeof(g_last_error), "%s failed: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+    return ZK_ERR_HIP;
+}
+}  // namespace zk
+#define ZK_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return zk::hip_fail(e_, #call, __FILE__, __LINE__); } while (0)
+#define ZK_TRY(call) do { int rc_ = (call); if (rc_ != ZK_OK) return rc_; } while (0)
+
+static inline uint32_t zk_div_up(uint64_t a, uint32_t b) { return (uint32_t)((a + b - 1) / b); }

@@ -1,0 +1,256 @@
+// ntt.hpp -- Fr radix-2 NTT over the libfqfft evaluation domain {omega_m^j}, and the
+// R1CS witness -> QAP "H polynomial" pipeline built on it.
+//
+// Replaces (reference call sites; the bodies live in the ABSENT libfqfft / libsnark forks):
+//   get_domain -> basic_radix2_domain / recursive_domain      src/stubs.cpp:61-75
+//   r1cs_to_qap_witness_map(domain, cs, w, aA, aB, aH)        r1cs_gg_ppzksnark_zok.tcc:461-468
+// Semantics follow SURVEY.md Appendix A.2/A.3: FFT, iFFT (x 1/m), cosetFFT (g = 5), icosetFFT,
+// divide_by_Z_on_coset.
+//
+// Kernel shape (HBM-bound, 32 B elements): a transform of size m = 2^logm is done in passes; each
+// pass loads a tile of 2^TILE_LOG elements into LDS (struct-of-limbs layout: 8 planes of u32, so a
+// wave's 64 lanes hit 64 consecutive banks), runs k butterfly stages there, and writes the tile
+// back.  Pass 0 does the bit-reversal permutation on load, later passes gather NCOL-wide contiguous
+// column groups (>= 256 B per row) so that strided stages still move whole cache lines.
+// Scaling vectors (1/m, coset powers) are fused into the first load / last store.
+#pragma once
+#include "bn254.hpp"
+#include "common.hpp"
+
+namespace zk {
+
+constexpr int NTT_TILE_LOG = 11;                 // 2048 elements = 64 KiB of LDS per workgroup
+constexpr int NTT_TILE = 1 << NTT_TILE_LOG;
+constexpr int NTT_THREADS = 256;
+constexpr int NTT_MIN_LOGC = 3;                  // >= 8 columns = 256 contiguous bytes per tile row
+
+static ZK_HD uint32_t bitrev32(uint32_t v, uint32_t bits) {
+    uint32_t r = 0;
+    for (uint32_t i = 0; i < bits; i++) { r = (r << 1) | (v & 1); v >>= 1; }
+    return r;
+}
+
+// One pass = stages s0+1 .. s0+k of the decimation-in-time transform.
+//   tile element e -> column c = e & (ncol-1), row q = e >> logc
+//   global index    = (h << (s0+k)) | (q << s0) | (lb*ncol + c)        (h, lb from blockIdx)
+//   src of pass 0   = bitrev(global index)      (ncol = 1, s0 = 0)
+// pre[]  (nullable) multiplies input element with natural index i by pre[i]  (coset shift g^i)
+// post[] (nullable) multiplies output element i by post[i]                   (1/m, g^-i/m, ...)
+__global__ void __launch_bounds__(NTT_THREADS)
+k_ntt_pass(const fe *__restrict__ in, fe *__restrict__ out, const fe *__restrict__ tw,
+           uint32_t logm, uint32_t s0, uint32_t k, uint32_t logc, int bitrev_load,
+           const fe *__restrict__ pre, const fe *__restrict__ post) {
+    __shared__ uint32_t sh[8][NTT_TILE];
+    const uint32_t tile = 1u << (k + logc), ncol = 1u << logc;
+    const uint32_t nlb = (1u << s0) >> logc;                  // column groups per high index
+    const uint32_t lb = blockIdx.x & (nlb - 1), h = blockIdx.x / nlb;
+    const uint32_t base = (h << (s0 + k)) | (lb << logc);
+
+    for (uint32_t e = threadIdx.x; e < tile; e += blockDim.x) {
+        uint32_t idx = base | ((e >> logc) << s0) | (e & (ncol - 1));
+        uint32_t src = bitrev_load ? bitrev32(idx, logm) : idx;
+        fe v = in[src];
+        if (pre) v = Fr::mul(v, pre[src]);
+#pragma unroll
+        for (int l = 0; l < 8; l++) sh[l][e] = v.l[l];
+    }
+    __syncthreads();
+    for (uint32_t s = 1; s <= k; s++) {
+        const uint32_t half = 1u << (s - 1), S = s0 + s;
+        for (uint32_t bf = threadIdx.x; bf < (tile >> 1); bf += blockDim.x) {
+            uint32_t c = bf & (ncol - 1), q = bf >> logc;
+            uint32_t jm = q & (half - 1), grp = q >> (s - 1);
+            uint32_t eu = (((grp << s) | jm) << logc) | c, ev = eu + (half << logc);
+            uint32_t j = (jm << s0) | ((lb << logc) | c);      // index inside the half-group of stage S
+            fe w = tw[(size_t)j << (logm - S)];
+            fe u, v;
+#pragma unroll
+            for (int l = 0; l < 8; l++) { u.l[l] = sh[l][eu]; v.l[l] = sh[l][ev]; }
+            v = Fr::mul(v, w);
+            fe a = Fr::add(u, v), b = Fr::sub(u, v);
+#pragma unroll
+            for (int l = 0; l < 8; l++) { sh[l][eu] = a.l[l]; sh[l][ev] = b.l[l]; }
+        }
+        __syncthreads();
+    }
+    for (uint32_t e = threadIdx.x; e < tile; e += blockDim.x) {
+        uint32_t idx = base | ((e >> logc) << s0) | (e & (ncol - 1));
+        fe v;
+#pragma unroll
+        for (int l = 0; l < 8; l++) v.l[l] = sh[l][e];
+        if (post) v = Fr::mul(v, post[idx]);
+        out[idx] = v;
+    }
+}
+
+// tables: tw[i] = w^i (i < m/2); geo[i] = s * g^i (i < m).  One thread per 256-element run.
+__global__ void k_fill_geometric(fe *out, uint32_t n, fe g, fe s) {
+    uint32_t run = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t i0 = run * 256;
+    if (i0 >= n) return;
+    fe t = Fr::mul(Fr::pow_u64(g, i0), s);
+    uint32_t end = i0 + 256 < n ? i0 + 256 : n;
+    for (uint32_t i = i0; i < end; i++) { out[i] = t; t = Fr::mul(t, g); }
+}
+
+// H on the coset: a[i] = (a[i] * b[i] - c[i]) * zinv     (divide_by_Z_on_coset fused)
+__global__ void k_pointwise_h(fe *a, const fe *b, const fe *c, fe zinv, uint32_t m) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    a[i] = Fr::mul(Fr::sub(Fr::mul(a[i], b[i]), c[i]), zinv);
+}
+
+struct NttTables {
+    uint32_t logm = 0;
+    fe *tw_fwd = nullptr, *tw_inv = nullptr;   // m/2 each
+    fe *coset_fwd = nullptr;                   // g^i            (cosetFFT pre-scale)
+    fe *inv_m = nullptr;                       // 1/m            (iFFT post-scale)
+    fe *icoset = nullptr;                      // g^-i / m       (icosetFFT post-scale)
+    fe *inv_then_coset = nullptr;              // g^i / m        (iFFT followed by cosetFFT, fused)
+    fe zinv;                                   // (g^m - 1)^-1
+};
+
+static inline fe fr_domain_root(uint32_t logm) {
+    // omega_{2^28} = 5^((r-1)/2^28)  (libff alt_bn128 Fr root_of_unity), canonical limbs
+    fe w; const uint32_t c[8] = {0x725b19f0u, 0x9bd61b6eu, 0x41112ed4u, 0x402d111eu, 0x8ef62abcu, 0x00e0a7ebu, 0xa58a7e85u, 0x2a3c09f0u};
+    for (int i = 0; i < 8; i++) w.l[i] = c[i];
+    w = Fr::to_mont(w);
+    for (uint32_t i = logm; i < 28; i++) w = Fr::sqr(w);
+    return w;
+}
+
+static inline int ntt_tables_free(NttTables &t) {
+    if (t.tw_fwd) hipFree(t.tw_fwd);
+    if (t.tw_inv) hipFree(t.tw_inv);
+    if (t.coset_fwd) hipFree(t.coset_fwd);
+    if (t.inv_m) hipFree(t.inv_m);
+    if (t.icoset) hipFree(t.icoset);
+    if (t.inv_then_coset) hipFree(t.inv_then_coset);
+    t = NttTables();
+    return ZK_OK;
+}
+
+static inline int ntt_tables_create(NttTables &t, uint32_t logm, hipStream_t st) {
+    if (logm > 28) return ZK_ERR_ARG;
+    t.logm = logm;
+    const uint32_t m = 1u << logm, half = m > 1 ? m / 2 : 1;
+    ZK_HIP(hipMalloc(&t.tw_fwd, sizeof(fe) * half));
+    ZK_HIP(hipMalloc(&t.tw_inv, sizeof(fe) * half));
+    ZK_HIP(hipMalloc(&t.coset_fwd, sizeof(fe) * m));
+    ZK_HIP(hipMalloc(&t.inv_m, sizeof(fe) * m));
+    ZK_HIP(hipMalloc(&t.icoset, sizeof(fe) * m));
+    ZK_HIP(hipMalloc(&t.inv_then_coset, sizeof(fe) * m));
+    const fe w = fr_domain_root(logm), wi = Fr::inv(w), g = Fr::from_u64(5), gi = Fr::inv(g);
+    const fe mi = Fr::inv(Fr::from_u64(m)), one = Fr::one();
+    t.zinv = Fr::inv(Fr::sub(Fr::pow_u64(g, m), one));
+    auto fill = [&](fe *dst, uint32_t n, const fe &base, const fe &scale) {
+        uint32_t runs = zk_div_up(n, 256);
+        ZK_LAUNCH(k_fill_geometric, zk_div_up(runs, 64), 64, st, dst, n, base, scale);
+    };
+    fill(t.tw_fwd, half, w, one);
+    fill(t.tw_inv, half, wi, one);
+    fill(t.coset_fwd, m, g, one);
+    fill(t.inv_m, m, one, mi);
+    fill(t.icoset, m, gi, mi);
+    fill(t.inv_then_coset, m, g, mi);
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+}
+
+// out <- transform(in); in and out must be different buffers (pass 0 permutes).  `pre`/`post` as in k_ntt_pass.
+static inline int ntt_run(const NttTables &t, const fe *in, fe *out, bool inverse,
+                          const fe *pre, const fe *post, hipStream_t st) {
+    const uint32_t logm = t.logm, m = 1u << logm;
+    const fe *tw = inverse ? t.tw_inv : t.tw_fwd;
+    if (logm == 0) {   // size-1 transform is the identity (times scaling)
+        uint32_t k0 = 0;
+        ZK_LAUNCH_SYNC(k_ntt_pass, 1, NTT_THREADS, st, in, out, tw, logm, 0u, k0, 0u, 1, pre, post);
+        return ZK_OK;
+    }
+    const uint32_t k0 = logm < (uint32_t)NTT_TILE_LOG ? logm : NTT_TILE_LOG;
+    uint32_t rem = logm - k0;
+    const uint32_t kmax = NTT_TILE_LOG - NTT_MIN_LOGC;
+    uint32_t npass = (rem + kmax - 1) / kmax;
+    ZK_LAUNCH_SYNC(k_ntt_pass, m >> k0, NTT_THREADS, st, in, out, tw, logm, 0u, k0, 0u, 1, pre,
+                   rem == 0 ? post : (const fe *)nullptr);
+    uint32_t s0 = k0;
+    while (rem) {
+        uint32_t k = (rem + npass - 1) / npass;
+        uint32_t logc = NTT_TILE_LOG - k;
+        if (logc > s0) logc = s0;
+        rem -= k; npass--;
+        ZK_LAUNCH_SYNC(k_ntt_pass, m >> (k + logc), NTT_THREADS, st, (const fe *)out, out, tw, logm, s0, k, logc, 0,
+                       (const fe *)nullptr, rem == 0 ? post : (const fe *)nullptr);
+        s0 += k;
+    }
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// Row evaluation  a_j = <A_j, w>  over CSR (thread per short row; long rows go through chunks).
+constexpr uint32_t SPMV_LONG_ROW = 64;        // rows with more terms are split into chunks
+constexpr uint32_t SPMV_CHUNK = 4096;         // terms per chunk (one workgroup each)
+
+static ZK_HD bool fr_is_one(const fe &a) {
+    uint32_t t = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) t |= a.l[i] ^ FrParams::one(i);
+    return t == 0;
+}
+static ZK_D fe spmv_term(const fe &coef, const fe &x) { return fr_is_one(coef) ? x : Fr::mul(coef, x); }
+
+__global__ void k_spmv_rows(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ col,
+                            const fe *__restrict__ coeff, const fe *__restrict__ w, fe *__restrict__ out, uint32_t n_rows) {
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_rows) return;
+    uint32_t b = row_ptr[j], e = row_ptr[j + 1];
+    if (e - b > SPMV_LONG_ROW) return;                     // written by k_spmv_long_finish
+    fe acc = Fr::zero();
+    for (uint32_t k = b; k < e; k++) acc = Fr::add(acc, spmv_term(coeff[k], w[col[k]]));
+    out[j] = acc;
+}
+
+// one workgroup per chunk of a long row: strided partial sums, then an LDS tree
+__global__ void __launch_bounds__(256)
+k_spmv_long_chunks(const uint32_t *__restrict__ chunk_begin, const uint32_t *__restrict__ chunk_end,
+                   const uint32_t *__restrict__ col, const fe *__restrict__ coeff, const fe *__restrict__ w,
+                   fe *__restrict__ partial) {
+    __shared__ uint32_t sh[8][256];
+    const uint32_t b = chunk_begin[blockIdx.x], e = chunk_end[blockIdx.x];
+    fe acc = Fr::zero();
+    for (uint32_t k = b + threadIdx.x; k < e; k += blockDim.x) acc = Fr::add(acc, spmv_term(coeff[k], w[col[k]]));
+#pragma unroll
+    for (int l = 0; l < 8; l++) sh[l][threadIdx.x] = acc.l[l];
+    __syncthreads();
+    for (uint32_t s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            fe o;
+#pragma unroll
+            for (int l = 0; l < 8; l++) o.l[l] = sh[l][threadIdx.x + s];
+            acc = Fr::add(acc, o);
+#pragma unroll
+            for (int l = 0; l < 8; l++) sh[l][threadIdx.x] = acc.l[l];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+
+// thread per long row: sum its chunk partials (chunks of a row are consecutive)
+__global__ void k_spmv_long_finish(const uint32_t *__restrict__ long_row, const uint32_t *__restrict__ long_first_chunk,
+                                   const fe *__restrict__ partial, fe *__restrict__ out, uint32_t n_long) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_long) return;
+    fe acc = Fr::zero();
+    for (uint32_t k = long_first_chunk[i]; k < long_first_chunk[i + 1]; k++) acc = Fr::add(acc, partial[k]);
+    out[long_row[i]] = acc;
+}
+
+// aA[nC + i] = w[i], i = 0..nIn  (input-consistency rows, Appendix A.3 step 1); rest of the pad stays 0
+__global__ void k_set_input_rows(fe *aA, const fe *w, uint32_t nC, uint32_t nIn) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= nIn) aA[nC + i] = w[i];
+}
+
+}  // namespace zk

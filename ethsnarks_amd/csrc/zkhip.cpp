@@ -1,0 +1,633 @@
+// zkhip.cpp -- C ABI (include/zkhip.h) of the MI355X Groth16 proving backend.
+// Compiled as HIP for gfx950 (see Makefile).  Host-side restatement of the reference's driver
+//   r1cs_gg_ppzksnark_zok_prover   src/r1cs_gg_ppzksnark_zok/r1cs_gg_ppzksnark_zok.tcc:451-550
+//   pk_nozk stream operators       ...tcc:108-143
+//   proof_to_json                  src/export.cpp:20-121
+// around the kernels of ntt.hpp / msm.hpp.  No CPU compute path exists in this library.
+#include <string>
+#include <vector>
+#include <chrono>
+#include <string.h>
+#include <stdlib.h>
+
+#include "common.hpp"
+#include "bn254.hpp"
+#include "ntt.hpp"
+#include "msm.hpp"
+#include "../../include/zkhip.h"
+
+namespace zk { thread_local char g_last_error[256] = ""; }
+using namespace zk;
+
+static int fail(int code, const char *msg) { snprintf(g_last_error, sizeof(g_last_error), "%s", msg); return code; }
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+static_assert(sizeof(G1::Affine) == 64 && sizeof(G2::Affine) == 128, "affine layouts must match the .raw / libff memory image");
+static_assert(sizeof(G1::XYZZ) == 128 && sizeof(G2::XYZZ) == 256, "XYZZ layouts");
+static_assert(sizeof(zk_partials) == 640, "zk_partials layout");
+
+// ================================================================ library / device
+extern "C" const char *zk_version(void) {
+#ifdef ZK_EMUL
+    return "zkhip 0.1.0 (CPU EMULATION BUILD - tests only)";
+#else
+    return "zkhip 0.1.0 (gfx950)";
+#endif
+}
+extern "C" const char *zk_strerror(int code) {
+    switch (code) {
+    case ZK_OK: return "ok";
+    case ZK_ERR_ARG: return "invalid argument";
+    case ZK_ERR_IO: return "file i/o error";
+    case ZK_ERR_FORMAT: return "malformed proving key stream";
+    case ZK_ERR_HIP: return "HIP runtime error";
+    case ZK_ERR_NOMEM: return "out of memory";
+    case ZK_ERR_SHAPE: return "proving key does not match the constraint system";
+    case ZK_ERR_DEGREE: return "H polynomial has wrong degree (witness does not satisfy the R1CS)";
+    case ZK_ERR_NODEVICE: return "no HIP device";
+    case ZK_ERR_BUFFER: return "output buffer too small";
+    default: return "unknown error";
+    }
+}
+extern "C" const char *zk_last_error(void) { return g_last_error; }
+extern "C" int zk_device_count(int *count) {
+    if (!count) return ZK_ERR_ARG;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return fail(ZK_ERR_NODEVICE, "hipGetDeviceCount failed: no usable HIP device"); }
+    *count = n;
+    return ZK_OK;
+}
+static int use_device(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(ZK_ERR_NODEVICE, "no HIP device (this library has no CPU path)");
+    if (device < 0 || device >= n) return fail(ZK_ERR_ARG, "device ordinal out of range");
+    ZK_HIP(hipSetDevice(device));
+    return ZK_OK;
+}
+
+// ================================================================ proving key (host)
+struct zk_pk {
+    G1::Affine alpha_g1, beta_g1, delta_g1;
+    G2::Affine beta_g2, delta_g2;
+    uint32_t a_domain = 0, b_domain = 0;
+    std::vector<uint32_t> a_idx, b_idx;
+    std::vector<G1::Affine> a_val, H, L;
+    std::vector<G2::Affine> b_val;
+};
+
+extern "C" int zk_pk_from_parts(const uint64_t *alpha_g1, const uint64_t *beta_g1, const uint64_t *beta_g2,
+                                const uint64_t *delta_g1, const uint64_t *delta_g2,
+                                uint32_t a_domain, uint32_t nA, const uint32_t *a_idx, const uint64_t *a_val,
+                                uint32_t b_domain, uint32_t nB, const uint32_t *b_idx, const uint64_t *b_val,
+                                uint32_t nH, const uint64_t *H, uint32_t nL, const uint64_t *L, zk_pk **out) {
+    if (!alpha_g1 || !beta_g1 || !beta_g2 || !delta_g1 || !delta_g2 || !out) return fail(ZK_ERR_ARG, "null argument");
+    if ((nA && (!a_idx || !a_val)) || (nB && (!b_idx || !b_val)) || (nH && !H) || (nL && !L)) return fail(ZK_ERR_ARG, "null query array");
+    zk_pk *pk = new (std::nothrow) zk_pk();
+    if (!pk) return ZK_ERR_NOMEM;
+    memcpy(&pk->alpha_g1, alpha_g1, 64); memcpy(&pk->beta_g1, beta_g1, 64); memcpy(&pk->beta_g2, beta_g2, 128);
+    memcpy(&pk->delta_g1, delta_g1, 64); memcpy(&pk->delta_g2, delta_g2, 128);
+    pk->a_domain = a_domain; pk->b_domain = b_domain;
+    pk->a_idx.assign(a_idx, a_idx + nA); pk->b_idx.assign(b_idx, b_idx + nB);
+    pk->a_val.resize(nA); if (nA) memcpy(pk->a_val.data(), a_val, 64 * (size_t)nA);
+    pk->b_val.resize(nB); if (nB) memcpy(pk->b_val.data(), b_val, 128 * (size_t)nB);
+    pk->H.resize(nH); if (nH) memcpy(pk->H.data(), H, 64 * (size_t)nH);
+    pk->L.resize(nL); if (nL) memcpy(pk->L.data(), L, 64 * (size_t)nL);
+    for (uint32_t k = 0; k < nA; k++) if (a_idx[k] >= a_domain || (k && a_idx[k] <= a_idx[k - 1])) { delete pk; return fail(ZK_ERR_ARG, "A_query indices must be ascending and inside the domain"); }
+    for (uint32_t k = 0; k < nB; k++) if (b_idx[k] >= b_domain || (k && b_idx[k] <= b_idx[k - 1])) { delete pk; return fail(ZK_ERR_ARG, "B_query indices must be ascending and inside the domain"); }
+    *out = pk;
+    return ZK_OK;
+}
+extern "C" int zk_pk_sizes(const zk_pk *pk, uint32_t s[6]) {
+    if (!pk || !s) return ZK_ERR_ARG;
+    s[0] = pk->a_domain; s[1] = (uint32_t)pk->a_idx.size(); s[2] = pk->b_domain; s[3] = (uint32_t)pk->b_idx.size();
+    s[4] = (uint32_t)pk->H.size(); s[5] = (uint32_t)pk->L.size();
+    return ZK_OK;
+}
+extern "C" const void *zk_pk_part(const zk_pk *pk, int which) {
+    if (!pk) return nullptr;
+    switch (which) {
+    case 0: return &pk->alpha_g1; case 1: return &pk->beta_g1; case 2: return &pk->beta_g2;
+    case 3: return &pk->delta_g1; case 4: return &pk->delta_g2;
+    case 5: return pk->a_idx.data(); case 6: return pk->a_val.data(); case 7: return pk->b_idx.data(); case 8: return pk->b_val.data();
+    case 9: return pk->H.data(); case 10: return pk->L.data(); default: return nullptr;
+    }
+}
+extern "C" void zk_pk_free(zk_pk *pk) { delete pk; }
+
+// ---- .raw stream, upstream libff layout under BINARY_OUTPUT + MONTGOMERY_OUTPUT + NO_PT_COMPRESSION
+// (CMakeLists.txt:115-131,186-188): point = ASCII '0'/'1' infinity flag + raw Montgomery limbs
+// (G1: X Y; G2: X.c0 X.c1 Y.c0 Y.c1); infinity carries affine X = 0, Y = 1; vector = decimal size
+// "\n" elements; sparse_vector = domain "\n" count "\n" indices (one per line) count "\n" elements.
+namespace {
+struct RawReader {
+    FILE *f; bool bad = false;
+    template <class P> void point(P &p) {
+        int c = fgetc(f);
+        if (c != '0' && c != '1') { bad = true; return; }
+        if (fread(&p, sizeof(P), 1, f) != 1) { bad = true; return; }
+        if (c == '1') memset(&p, 0, sizeof(P));
+    }
+    uint64_t size() {
+        uint64_t v = 0; int c, nd = 0;
+        while ((c = fgetc(f)) >= '0' && c <= '9') { v = v * 10 + (uint64_t)(c - '0'); if (++nd > 12) { bad = true; return 0; } }
+        if (c != '\n' || nd == 0) bad = true;
+        return v;
+    }
+    template <class P> void points(std::vector<P> &v, uint64_t n) {
+        if (bad) return;
+        if (n > (1ull << 28) + 1) { bad = true; return; }
+        v.resize(n);
+        for (uint64_t i = 0; i < n && !bad; i++) point(v[i]);
+    }
+};
+template <class P> void raw_put_point(FILE *f, const P &p, bool inf, const P &inf_image) {
+    fputc(inf ? '1' : '0', f);
+    fwrite(inf ? &inf_image : &p, sizeof(P), 1, f);
+}
+}  // namespace
+
+extern "C" int zk_pk_load_raw(const char *path, int codec, zk_pk **out) {
+    if (!path || !out) return fail(ZK_ERR_ARG, "null argument");
+    if (codec != ZK_CODEC_ALT_BN128) return fail(ZK_ERR_ARG, "unsupported codec (only ZK_CODEC_ALT_BN128)");
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(ZK_ERR_IO, "cannot open proving key file");       // reference: assert(fh.is_open()), utils.hpp:180
+    zk_pk *pk = new (std::nothrow) zk_pk();
+    if (!pk) { fclose(f); return ZK_ERR_NOMEM; }
+    RawReader r{f};
+    r.point(pk->alpha_g1); r.point(pk->beta_g1); r.point(pk->beta_g2); r.point(pk->delta_g1); r.point(pk->delta_g2);
+    auto sparse = [&](uint32_t &domain, std::vector<uint32_t> &idx, auto &vals) {
+        if (r.bad) return;
+        domain = (uint32_t)r.size();
+        uint64_t n = r.size();
+        if (r.bad || n > (1ull << 28) + 1) { r.bad = true; return; }
+        idx.resize(n);
+        for (uint64_t i = 0; i < n && !r.bad; i++) {
+            idx[i] = (uint32_t)r.size();
+            if (idx[i] >= domain || (i && idx[i] <= idx[i - 1])) r.bad = true;
+        }
+        uint64_t nv = r.size();
+        if (nv != n) r.bad = true;
+        r.points(vals, nv);
+    };
+    sparse(pk->a_domain, pk->a_idx, pk->a_val);
+    sparse(pk->b_domain, pk->b_idx, pk->b_val);
+    if (!r.bad) r.points(pk->H, r.size());
+    if (!r.bad) r.points(pk->L, r.size());
+    fclose(f);
+    if (r.bad) { delete pk; return fail(ZK_ERR_FORMAT, "malformed .raw proving key stream"); }
+    *out = pk;
+    return ZK_OK;
+}
+
+extern "C" int zk_pk_save_raw(const zk_pk *pk, const char *path, int codec) {
+    if (!pk || !path) return fail(ZK_ERR_ARG, "null argument");
+    if (codec != ZK_CODEC_ALT_BN128) return fail(ZK_ERR_ARG, "unsupported codec");
+    FILE *f = fopen(path, "wb");
+    if (!f) return fail(ZK_ERR_IO, "cannot create proving key file");
+    G1::Affine i1; i1.x = Fq::zero(); i1.y = Fq::one();
+    G2::Affine i2; i2.x = Fq2::zero(); i2.y = Fq2::one();
+    auto p1 = [&](const G1::Affine &p) { raw_put_point(f, p, G1::is_inf(p), i1); };
+    auto p2 = [&](const G2::Affine &p) { raw_put_point(f, p, G2::is_inf(p), i2); };
+    p1(pk->alpha_g1); p1(pk->beta_g1); p2(pk->beta_g2); p1(pk->delta_g1); p2(pk->delta_g2);
+    fprintf(f, "%u\n%zu\n", pk->a_domain, pk->a_idx.size());
+    for (uint32_t i : pk->a_idx) fprintf(f, "%u\n", i);
+    fprintf(f, "%zu\n", pk->a_val.size());
+    for (auto &p : pk->a_val) p1(p);
+    fprintf(f, "%u\n%zu\n", pk->b_domain, pk->b_idx.size());
+    for (uint32_t i : pk->b_idx) fprintf(f, "%u\n", i);
+    fprintf(f, "%zu\n", pk->b_val.size());
+    for (auto &p : pk->b_val) p2(p);
+    fprintf(f, "%zu\n", pk->H.size());
+    for (auto &p : pk->H) p1(p);
+    fprintf(f, "%zu\n", pk->L.size());
+    for (auto &p : pk->L) p1(p);
+    bool bad = ferror(f) != 0;
+    if (fclose(f) != 0) bad = true;
+    return bad ? fail(ZK_ERR_IO, "write error") : ZK_OK;
+}
+
+// ================================================================ context
+namespace {
+struct DevCsr {
+    uint32_t n_rows = 0, nnz = 0, n_long = 0, n_chunks = 0;
+    uint32_t *row_ptr = nullptr, *col = nullptr, *long_row = nullptr, *long_first = nullptr, *chunk_begin = nullptr, *chunk_end = nullptr;
+    fe *coeff = nullptr, *partial = nullptr;
+    void release() {
+        void *p[] = {row_ptr, col, long_row, long_first, chunk_begin, chunk_end, coeff, partial};
+        for (void *q : p) if (q) hipFree(q);
+        *this = DevCsr();
+    }
+    int upload(const zk_csr *m, uint32_t V) {
+        n_rows = m->n_rows;
+        nnz = m->row_ptr[n_rows];
+        std::vector<uint32_t> lrow, lfirst, cb, ce;
+        for (uint32_t j = 0; j < n_rows; j++) {
+            uint32_t b = m->row_ptr[j], e = m->row_ptr[j + 1];
+            if (e < b || e > nnz) return fail(ZK_ERR_ARG, "CSR row_ptr not monotone");
+            if (e - b > SPMV_LONG_ROW) {
+                lrow.push_back(j); lfirst.push_back((uint32_t)cb.size());
+                for (uint32_t k = b; k < e; k += SPMV_CHUNK) { cb.push_back(k); ce.push_back(k + SPMV_CHUNK < e ? k + SPMV_CHUNK : e); }
+            }
+        }
+        lfirst.push_back((uint32_t)cb.size());
+        for (uint32_t k = 0; k < nnz; k++) if (m->col[k] > V) return fail(ZK_ERR_ARG, "CSR column index exceeds the number of variables");
+        n_long = (uint32_t)lrow.size(); n_chunks = (uint32_t)cb.size();
+        ZK_HIP(hipMalloc(&row_ptr, 4 * (size_t)(n_rows + 1)));
+        ZK_HIP(hipMalloc(&col, 4 * (size_t)(nnz + 1)));
+        ZK_HIP(hipMalloc(&coeff, 32 * (size_t)(nnz + 1)));
+        ZK_HIP(hipMemcpy(row_ptr, m->row_ptr, 4 * (size_t)(n_rows + 1), hipMemcpyHostToDevice));
+        if (nnz) {
+            ZK_HIP(hipMemcpy(col, m->col, 4 * (size_t)nnz, hipMemcpyHostToDevice));
+            ZK_HIP(hipMemcpy(coeff, m->coeff, 32 * (size_t)nnz, hipMemcpyHostToDevice));
+        }
+        ZK_HIP(hipMalloc(&long_row, 4 * (size_t)(n_long + 1)));
+        ZK_HIP(hipMalloc(&long_first, 4 * (size_t)(n_long + 1)));
+        ZK_HIP(hipMalloc(&chunk_begin, 4 * (size_t)(n_chunks + 1)));
+        ZK_HIP(hipMalloc(&chunk_end, 4 * (size_t)(n_chunks + 1)));
+        ZK_HIP(hipMalloc(&partial, 32 * (size_t)(n_chunks + 1)));
+        if (n_long) ZK_HIP(hipMemcpy(long_row, lrow.data(), 4 * (size_t)n_long, hipMemcpyHostToDevice));
+        ZK_HIP(hipMemcpy(long_first, lfirst.data(), 4 * (size_t)(n_long + 1), hipMemcpyHostToDevice));
+        if (n_chunks) {
+            ZK_HIP(hipMemcpy(chunk_begin, cb.data(), 4 * (size_t)n_chunks, hipMemcpyHostToDevice));
+            ZK_HIP(hipMemcpy(chunk_end, ce.data(), 4 * (size_t)n_chunks, hipMemcpyHostToDevice));
+        }
+        return ZK_OK;
+    }
+    // out[0..n_rows) = M * w
+    int enqueue(const fe *w, fe *out, hipStream_t st) const {
+        if (n_rows) ZK_LAUNCH(k_spmv_rows, zk_div_up(n_rows, 256), 256, st, (const uint32_t *)row_ptr, (const uint32_t *)col, (const fe *)coeff, w, out, n_rows);
+        if (n_chunks) {
+            ZK_LAUNCH_SYNC(k_spmv_long_chunks, n_chunks, 256, st, (const uint32_t *)chunk_begin, (const uint32_t *)chunk_end,
+                           (const uint32_t *)col, (const fe *)coeff, w, partial);
+            ZK_LAUNCH(k_spmv_long_finish, zk_div_up(n_long, 64), 64, st, (const uint32_t *)long_row, (const uint32_t *)long_first,
+                      (const fe *)partial, out, n_long);
+        }
+        ZK_HIP(hipGetLastError());
+        return ZK_OK;
+    }
+};
+
+__global__ void k_to_mont(fe *a, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = Fr::to_mont(a[i]);
+}
+__global__ void k_field_mul(const fe *a, const fe *b, fe *o, uint32_t n, int field) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) o[i] = field ? Fq::mul(a[i], b[i]) : Fr::mul(a[i], b[i]);
+}
+
+template <class T> int dev_upload(T **dst, const T *src, size_t n) {
+    ZK_HIP(hipMalloc(dst, sizeof(T) * (n ? n : 1)));
+    if (n) ZK_HIP(hipMemcpy(*dst, src, sizeof(T) * n, hipMemcpyHostToDevice));
+    return ZK_OK;
+}
+struct Range { uint32_t lo, hi; uint32_t n() const { return hi - lo; } };
+Range shard_range(uint32_t n, uint32_t rank, uint32_t count) {
+    return Range{(uint32_t)((uint64_t)n * rank / count), (uint32_t)((uint64_t)n * (rank + 1) / count)};
+}
+}  // namespace
+
+struct zk_ctx {
+    int device = 0;
+    uint32_t nC = 0, nIn = 0, V = 0, m = 0, logm = 0;
+    zk_config cfg{};
+    G1::Affine alpha_g1; G2::Affine beta_g2;
+    // shard-local base ranges (whole query when unsharded)
+    Range rA{}, rB{}, rH{}, rL{};
+    G1::Affine *dA = nullptr, *dH = nullptr, *dL = nullptr; G2::Affine *dB = nullptr;
+    uint32_t *dA_idx = nullptr, *dB_idx = nullptr;
+    DevCsr cA, cB, cC;
+    fe *d_w = nullptr, *d_a = nullptr, *d_b = nullptr, *d_c = nullptr, *d_t = nullptr;
+    fe *h_w = nullptr;                         // pinned staging for the witness
+    fe *h_tail = nullptr;                      // pinned: h[m-1] for the degree check
+    NttTables tab;
+    MsmWork<G1> mA, mH, mL; MsmWork<G2> mB;
+    hipStream_t s_main = nullptr, s_a = nullptr, s_b = nullptr, s_l = nullptr;
+    hipEvent_t ev_start = nullptr, ev_w = nullptr, ev_h = nullptr, ev_a0 = nullptr, ev_a1 = nullptr, ev_b0 = nullptr, ev_b1 = nullptr,
+               ev_l0 = nullptr, ev_l1 = nullptr, ev_h1 = nullptr;
+    ~zk_ctx() {
+        hipSetDevice(device);
+        void *dev[] = {dA, dH, dL, dB, dA_idx, dB_idx, d_w, d_a, d_b, d_c, d_t};
+        for (void *p : dev) if (p) hipFree(p);
+        if (h_w) hipHostFree(h_w);
+        if (h_tail) hipHostFree(h_tail);
+        cA.release(); cB.release(); cC.release();
+        ntt_tables_free(tab);
+        mA.release(); mH.release(); mL.release(); mB.release();
+        hipStream_t ss[] = {s_main, s_a, s_b, s_l};
+        for (auto s : ss) if (s) hipStreamDestroy(s);
+        hipEvent_t ee[] = {ev_start, ev_w, ev_h, ev_a0, ev_a1, ev_b0, ev_b1, ev_l0, ev_l1, ev_h1};
+        for (auto e : ee) if (e) hipEventDestroy(e);
+    }
+};
+
+extern "C" uint32_t zk_domain_size(uint32_t nC, uint32_t nIn) {
+    uint32_t v = nC + nIn + 1;                                   // src/stubs.cpp:65
+    v--; v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16; v++;   // roundUpToNearestPowerOf2, :49-59
+    return v;
+}
+
+static int ctx_build(zk_ctx *c, const zk_pk *pk, const zk_csr *A, const zk_csr *B, const zk_csr *C) {
+    ZK_TRY(use_device(c->device));
+    const uint32_t m = c->m, V = c->V, nIn = c->nIn;
+    const uint32_t G = c->cfg.shard_count > 1 ? c->cfg.shard_count : 1, r = G > 1 ? c->cfg.shard_rank : 0;
+    c->rA = shard_range((uint32_t)pk->a_val.size(), r, G);
+    c->rB = shard_range((uint32_t)pk->b_val.size(), r, G);
+    c->rH = shard_range(m - 1, r, G);
+    c->rL = shard_range(V - nIn, r, G);
+    ZK_TRY(dev_upload(&c->dA, pk->a_val.data() + c->rA.lo, c->rA.n()));
+    ZK_TRY(dev_upload(&c->dA_idx, pk->a_idx.data() + c->rA.lo, c->rA.n()));
+    ZK_TRY(dev_upload(&c->dB, pk->b_val.data() + c->rB.lo, c->rB.n()));
+    ZK_TRY(dev_upload(&c->dB_idx, pk->b_idx.data() + c->rB.lo, c->rB.n()));
+    ZK_TRY(dev_upload(&c->dH, pk->H.data() + c->rH.lo, c->rH.n()));
+    ZK_TRY(dev_upload(&c->dL, pk->L.data() + c->rL.lo, c->rL.n()));
+    ZK_TRY(c->cA.upload(A, V)); ZK_TRY(c->cB.upload(B, V)); ZK_TRY(c->cC.upload(C, V));
+    ZK_HIP(hipMalloc(&c->d_w, 32 * (size_t)(V + 1)));
+    ZK_HIP(hipMalloc(&c->d_a, 32 * (size_t)m)); ZK_HIP(hipMalloc(&c->d_b, 32 * (size_t)m));
+    ZK_HIP(hipMalloc(&c->d_c, 32 * (size_t)m)); ZK_HIP(hipMalloc(&c->d_t, 32 * (size_t)m));
+    ZK_HIP(hipHostMalloc(&c->h_w, 32 * (size_t)(V + 1), hipHostMallocDefault));
+    ZK_HIP(hipHostMalloc(&c->h_tail, 32, hipHostMallocDefault));
+    ZK_HIP(hipStreamCreateWithFlags(&c->s_main, hipStreamNonBlocking));
+    ZK_HIP(hipStreamCreateWithFlags(&c->s_a, hipStreamNonBlocking));
+    ZK_HIP(hipStreamCreateWithFlags(&c->s_b, hipStreamNonBlocking));
+    ZK_HIP(hipStreamCreateWithFlags(&c->s_l, hipStreamNonBlocking));
+    hipEvent_t *ee[] = {&c->ev_start, &c->ev_w, &c->ev_h, &c->ev_a0, &c->ev_a1, &c->ev_b0, &c->ev_b1, &c->ev_l0, &c->ev_l1, &c->ev_h1};
+    for (auto e : ee) ZK_HIP(hipEventCreate(e));
+    ZK_TRY(ntt_tables_create(c->tab, c->logm, c->s_main));
+    ZK_TRY(c->mA.alloc(c->rA.n(), c->cfg.multi_exp_c));
+    ZK_TRY(c->mB.alloc(c->rB.n(), c->cfg.multi_exp_c));
+    ZK_TRY(c->mH.alloc(c->rH.n(), c->cfg.multi_exp_c));
+    ZK_TRY(c->mL.alloc(c->rL.n(), c->cfg.multi_exp_c));
+    ZK_HIP(hipStreamSynchronize(c->s_main));
+    return ZK_OK;
+}
+
+extern "C" int zk_ctx_create(const zk_pk *pk, const zk_csr *A, const zk_csr *B, const zk_csr *C,
+                             uint32_t nC, uint32_t nIn, uint32_t V, const zk_config *cfg, zk_ctx **out) {
+    if (!pk || !A || !B || !C || !out) return fail(ZK_ERR_ARG, "null argument");
+    if (A->n_rows != nC || B->n_rows != nC || C->n_rows != nC) return fail(ZK_ERR_ARG, "CSR row counts must equal nC");
+    if (nIn > V) return fail(ZK_ERR_ARG, "nIn > V");
+    if ((uint64_t)nC + nIn + 1 > (1ull << 28)) return fail(ZK_ERR_ARG, "domain exceeds 2^28 (2-adicity of r - 1)");
+    const uint32_t m = zk_domain_size(nC, nIn);
+    // the reference's DEBUG asserts, tcc:477-483, made unconditional
+    if (pk->a_domain != V + 1 || pk->b_domain != V + 1 || pk->H.size() != (size_t)m - 1 || pk->L.size() != (size_t)(V - nIn))
+        return fail(ZK_ERR_SHAPE, "proving key shape does not match (A/B domain = V+1, |H| = m-1, |L| = V-nIn)");
+    zk_ctx *c = new (std::nothrow) zk_ctx();
+    if (!c) return ZK_ERR_NOMEM;
+    if (cfg) c->cfg = *cfg;
+    if (c->cfg.shard_count > 1 && c->cfg.shard_rank >= c->cfg.shard_count) { delete c; return fail(ZK_ERR_ARG, "shard_rank >= shard_count"); }
+    c->device = (int)c->cfg.device;
+    c->nC = nC; c->nIn = nIn; c->V = V; c->m = m;
+    while ((1u << c->logm) < m) c->logm++;
+    c->alpha_g1 = pk->alpha_g1; c->beta_g2 = pk->beta_g2;
+    int rc = ctx_build(c, pk, A, B, C);
+    if (rc != ZK_OK) { delete c; return rc; }
+    *out = c;
+    return ZK_OK;
+}
+extern "C" void zk_ctx_destroy(zk_ctx *ctx) { delete ctx; }
+
+// ---- "Compute the polynomial H" (tcc:460-475) on s_main; result in d_t (natural order), h[m-1] copied to h_tail
+static int enqueue_compute_h(zk_ctx *c) {
+    hipStream_t st = c->s_main;
+    const uint32_t m = c->m;
+    ZK_HIP(hipMemsetAsync(c->d_a, 0, 32 * (size_t)m, st));
+    ZK_HIP(hipMemsetAsync(c->d_b, 0, 32 * (size_t)m, st));
+    ZK_HIP(hipMemsetAsync(c->d_c, 0, 32 * (size_t)m, st));
+    ZK_TRY(c->cA.enqueue(c->d_w, c->d_a, st));
+    ZK_TRY(c->cB.enqueue(c->d_w, c->d_b, st));
+    ZK_TRY(c->cC.enqueue(c->d_w, c->d_c, st));
+    ZK_LAUNCH(k_set_input_rows, zk_div_up(c->nIn + 1, 64), 64, st, c->d_a, (const fe *)c->d_w, c->nC, c->nIn);
+    fe *polys[3] = {c->d_a, c->d_b, c->d_c};
+    for (fe *p : polys) {
+        ZK_TRY(ntt_run(c->tab, p, c->d_t, true, nullptr, c->tab.inv_then_coset, st));   // iFFT, then x g^i (cosetFFT pre-scale)
+        ZK_TRY(ntt_run(c->tab, c->d_t, p, false, nullptr, nullptr, st));               // FFT -> evaluations on the coset
+    }
+    ZK_LAUNCH(k_pointwise_h, zk_div_up(m, 256), 256, st, c->d_a, (const fe *)c->d_b, (const fe *)c->d_c, c->tab.zinv, m);
+    ZK_TRY(ntt_run(c->tab, c->d_a, c->d_t, true, nullptr, c->tab.icoset, st));          // icosetFFT
+    ZK_HIP(hipMemcpyAsync(c->h_tail, c->d_t + (m - 1), 32, hipMemcpyDeviceToHost, st));
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+}
+
+static int upload_witness(zk_ctx *c, const uint64_t *witness, int canonical) {
+    memcpy(c->h_w, witness, 32 * (size_t)(c->V + 1));
+    ZK_HIP(hipEventRecord(c->ev_start, c->s_main));
+    ZK_HIP(hipMemcpyAsync(c->d_w, c->h_w, 32 * (size_t)(c->V + 1), hipMemcpyHostToDevice, c->s_main));
+    if (canonical) ZK_LAUNCH(k_to_mont, zk_div_up(c->V + 1, 256), 256, c->s_main, c->d_w, c->V + 1);
+    ZK_HIP(hipEventRecord(c->ev_w, c->s_main));
+    return ZK_OK;
+}
+
+static void store_xyzz(uint64_t *dst, const G1::XYZZ &p) { memcpy(dst, &p, sizeof(p)); }
+static void store_xyzz(uint64_t *dst, const G2::XYZZ &p) { memcpy(dst, &p, sizeof(p)); }
+
+static int prove_partial_impl(zk_ctx *c, const uint64_t *witness, int canonical, zk_partials *out, zk_timings *tm) {
+    if (!c || !witness || !out) return fail(ZK_ERR_ARG, "null argument");
+    ZK_TRY(use_device(c->device));
+    ZK_TRY(upload_witness(c, witness, canonical));
+    // A-, B-, L-query only need the witness: run them beside the H pipeline on their own streams
+    ZK_HIP(hipStreamWaitEvent(c->s_a, c->ev_w, 0));
+    ZK_HIP(hipStreamWaitEvent(c->s_b, c->ev_w, 0));
+    ZK_HIP(hipStreamWaitEvent(c->s_l, c->ev_w, 0));
+    ZK_HIP(hipEventRecord(c->ev_a0, c->s_a));
+    ZK_TRY(c->mA.enqueue(c->dA, c->d_w, c->dA_idx, c->rA.n(), 0, c->s_a));              // tcc:488-495
+    ZK_HIP(hipEventRecord(c->ev_a1, c->s_a));
+    ZK_HIP(hipEventRecord(c->ev_b0, c->s_b));
+    ZK_TRY(c->mB.enqueue(c->dB, c->d_w, c->dB_idx, c->rB.n(), 0, c->s_b));              // tcc:499-506
+    ZK_HIP(hipEventRecord(c->ev_b1, c->s_b));
+    ZK_HIP(hipEventRecord(c->ev_l0, c->s_l));
+    ZK_TRY(c->mL.enqueue(c->dL, c->d_w + (c->nIn + 1) + c->rL.lo, nullptr, c->rL.n(), 0, c->s_l));   // tcc:522-530
+    ZK_HIP(hipEventRecord(c->ev_l1, c->s_l));
+    ZK_TRY(enqueue_compute_h(c));
+    ZK_HIP(hipEventRecord(c->ev_h, c->s_main));
+    ZK_TRY(c->mH.enqueue(c->dH, c->d_t + c->rH.lo, nullptr, c->rH.n(), 0, c->s_main));  // tcc:510-518
+    ZK_HIP(hipEventRecord(c->ev_h1, c->s_main));
+    ZK_HIP(hipStreamSynchronize(c->s_a)); ZK_HIP(hipStreamSynchronize(c->s_b));
+    ZK_HIP(hipStreamSynchronize(c->s_l)); ZK_HIP(hipStreamSynchronize(c->s_main));
+    if (!Fr::is_zero(*c->h_tail)) return fail(ZK_ERR_DEGREE, "h[m-1] != 0: the witness does not satisfy the constraint system");
+    double t0 = now_ms();
+    store_xyzz(out->At, c->mA.finish()); store_xyzz(out->Bt, c->mB.finish());
+    store_xyzz(out->Ht, c->mH.finish()); store_xyzz(out->Lt, c->mL.finish());
+    if (tm) {
+        memset(tm, 0, sizeof(*tm));
+        hipEventElapsedTime(&tm->h2d_witness, c->ev_start, c->ev_w);
+        hipEventElapsedTime(&tm->compute_h, c->ev_w, c->ev_h);
+        hipEventElapsedTime(&tm->a_query, c->ev_a0, c->ev_a1);
+        hipEventElapsedTime(&tm->b_query, c->ev_b0, c->ev_b1);
+        hipEventElapsedTime(&tm->l_query, c->ev_l0, c->ev_l1);
+        hipEventElapsedTime(&tm->h_query, c->ev_h, c->ev_h1);
+        float ta = 0, tb = 0, tl = 0, th = 0;
+        hipEventElapsedTime(&ta, c->ev_start, c->ev_a1); hipEventElapsedTime(&tb, c->ev_start, c->ev_b1);
+        hipEventElapsedTime(&tl, c->ev_start, c->ev_l1); hipEventElapsedTime(&th, c->ev_start, c->ev_h1);
+        tm->gpu_total = ta; if (tb > tm->gpu_total) tm->gpu_total = tb;
+        if (tl > tm->gpu_total) tm->gpu_total = tl; if (th > tm->gpu_total) tm->gpu_total = th;
+        tm->host_finish = (float)(now_ms() - t0);
+    }
+    return ZK_OK;
+}
+
+template <class F> static void canon4(uint64_t dst[4], const fe &mont) { fe c = F::from_mont(mont); memcpy(dst, c.l, 32); }
+static void put_g1(const G1::XYZZ &p, uint64_t x[4], uint64_t y[4], uint32_t *inf) {
+    G1::Affine a = G1::to_affine(p);
+    if (G1::is_inf(a)) { memset(x, 0, 32); memset(y, 0, 32); y[0] = 1; *inf = 1; return; }   // libff affine image of zero: (0, 1)
+    canon4<Fq>(x, a.x); canon4<Fq>(y, a.y); *inf = 0;
+}
+static void put_g2(const G2::XYZZ &p, uint64_t xc0[4], uint64_t xc1[4], uint64_t yc0[4], uint64_t yc1[4], uint32_t *inf) {
+    G2::Affine a = G2::to_affine(p);
+    if (G2::is_inf(a)) { memset(xc0, 0, 32); memset(xc1, 0, 32); memset(yc0, 0, 32); memset(yc1, 0, 32); yc0[0] = 1; *inf = 1; return; }
+    canon4<Fq>(xc0, a.x.c0); canon4<Fq>(xc1, a.x.c1); canon4<Fq>(yc0, a.y.c0); canon4<Fq>(yc1, a.y.c1); *inf = 0;
+}
+
+// "Compute the proof" tail, tcc:533-546: A = alpha + At, B = beta + Bt, C = Ht + Lt; partials folded in rank order
+extern "C" int zk_prove_combine(const zk_ctx *c, const zk_partials *parts, uint32_t count, zk_proof *out) {
+    if (!c || !parts || !count || !out) return fail(ZK_ERR_ARG, "null argument");
+    G1::XYZZ At = G1::infinity(), Ht = G1::infinity(), Lt = G1::infinity(); G2::XYZZ Bt = G2::infinity();
+    for (uint32_t i = 0; i < count; i++) {
+        G1::XYZZ a, h, l; G2::XYZZ b;
+        memcpy(&a, parts[i].At, sizeof(a)); memcpy(&b, parts[i].Bt, sizeof(b));
+        memcpy(&h, parts[i].Ht, sizeof(h)); memcpy(&l, parts[i].Lt, sizeof(l));
+        At = G1::add(At, a); Bt = G2::add(Bt, b); Ht = G1::add(Ht, h); Lt = G1::add(Lt, l);
+    }
+    G1::XYZZ gA = G1::madd(At, c->alpha_g1);
+    G2::XYZZ gB = G2::madd(Bt, c->beta_g2);
+    G1::XYZZ gC = G1::add(Ht, Lt);
+    memset(out, 0, sizeof(*out));
+    put_g1(gA, out->a_x, out->a_y, &out->a_inf);
+    put_g2(gB, out->b_x_c0, out->b_x_c1, out->b_y_c0, out->b_y_c1, &out->b_inf);
+    put_g1(gC, out->c_x, out->c_y, &out->c_inf);
+    return ZK_OK;
+}
+
+extern "C" int zk_prove_partial(zk_ctx *ctx, const uint64_t *witness, int canonical, zk_partials *out) {
+    return prove_partial_impl(ctx, witness, canonical, out, nullptr);
+}
+extern "C" int zk_prove_timed(zk_ctx *ctx, const uint64_t *witness, int canonical, zk_proof *out, zk_timings *t) {
+    if (!ctx || !out) return fail(ZK_ERR_ARG, "null argument");
+    if (ctx->cfg.shard_count > 1) return fail(ZK_ERR_ARG, "sharded context: use zk_prove_partial + zk_prove_combine");
+    zk_partials p;
+    ZK_TRY(prove_partial_impl(ctx, witness, canonical, &p, t));
+    double t0 = now_ms();
+    ZK_TRY(zk_prove_combine(ctx, &p, 1, out));
+    if (t) t->host_finish += (float)(now_ms() - t0);
+    return ZK_OK;
+}
+extern "C" int zk_prove(zk_ctx *ctx, const uint64_t *witness, int canonical, zk_proof *out) {
+    return zk_prove_timed(ctx, witness, canonical, out, nullptr);
+}
+
+// ================================================================ JSON (src/export.cpp:20-121)
+namespace {
+// HexStringFromBigint = mpz_get_str(., 16, .): lowercase, no leading zeros, zero prints "0"
+void hex_canon(std::string &s, const uint64_t v[4]) {
+    bool started = false;
+    for (int i = 3; i >= 0; i--) for (int sh = 60; sh >= 0; sh -= 4) {
+        unsigned d = (unsigned)(v[i] >> sh) & 15u;
+        if (d || started) { s.push_back("0123456789abcdef"[d]); started = true; }
+    }
+    if (!started) s.push_back('0');
+}
+void q(std::string &s, const uint64_t v[4]) { s += "\"0x"; hex_canon(s, v); s += "\""; }
+}  // namespace
+
+extern "C" int zk_proof_to_json(const zk_proof *p, const uint64_t *inputs, uint32_t nIn, int canonical,
+                                char *buf, size_t cap, size_t *len) {
+    if (!p || (nIn && !inputs) || !len) return fail(ZK_ERR_ARG, "null argument");
+    std::string s;
+    s.reserve(1024 + 70 * (size_t)nIn);
+    s += "{\n \"A\" :["; q(s, p->a_x); s += ", "; q(s, p->a_y);
+    s += "],\n \"B\"  :[["; q(s, p->b_x_c1); s += ", "; q(s, p->b_x_c0); s += "],\n ["; q(s, p->b_y_c1); s += ", "; q(s, p->b_y_c0);
+    s += "]],\n \"C\"  :["; q(s, p->c_x); s += ", "; q(s, p->c_y);
+    s += "],\n \"input\" :[";
+    for (uint32_t i = 0; i < nIn; i++) {
+        uint64_t v[4];
+        fe e; memcpy(e.l, inputs + 4 * (size_t)i, 32);
+        if (!canonical) e = Fr::from_mont(e);
+        memcpy(v, e.l, 32);
+        q(s, v);
+        if (i + 1 < nIn) s += ", ";
+    }
+    s += "]\n}";
+    *len = s.size();
+    if (!buf || cap < s.size() + 1) return fail(ZK_ERR_BUFFER, "JSON buffer too small");
+    memcpy(buf, s.data(), s.size()); buf[s.size()] = 0;
+    return ZK_OK;
+}
+
+// ================================================================ kernel-level entry points (tests / micro-benchmarks)
+extern "C" int zk_ntt(uint64_t *data, uint32_t logm, int inverse, int coset, int device) {
+    if (!data || logm > 28) return fail(ZK_ERR_ARG, "bad argument");
+    ZK_TRY(use_device(device));
+    NttTables tab; fe *d_in = nullptr, *d_out = nullptr;
+    const size_t bytes = 32ull << logm;
+    int rc = ntt_tables_create(tab, logm, nullptr);
+    if (rc == ZK_OK && hipMalloc(&d_in, bytes) != hipSuccess) rc = ZK_ERR_NOMEM;
+    if (rc == ZK_OK && hipMalloc(&d_out, bytes) != hipSuccess) rc = ZK_ERR_NOMEM;
+    if (rc == ZK_OK && hipMemcpy(d_in, data, bytes, hipMemcpyHostToDevice) != hipSuccess) rc = ZK_ERR_HIP;
+    if (rc == ZK_OK) {
+        const fe *pre = (!inverse && coset) ? tab.coset_fwd : nullptr;
+        const fe *post = inverse ? (coset ? tab.icoset : tab.inv_m) : nullptr;
+        rc = ntt_run(tab, d_in, d_out, inverse != 0, pre, post, nullptr);
+    }
+    if (rc == ZK_OK && hipDeviceSynchronize() != hipSuccess) rc = fail(ZK_ERR_HIP, "NTT kernels failed");
+    if (rc == ZK_OK && hipMemcpy(data, d_out, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = ZK_ERR_HIP;
+    if (d_in) hipFree(d_in);
+    if (d_out) hipFree(d_out);
+    ntt_tables_free(tab);
+    return rc;
+}
+
+extern "C" int zk_witness_map(zk_ctx *c, const uint64_t *witness, int canonical, uint64_t *h_out) {
+    if (!c || !witness || !h_out) return fail(ZK_ERR_ARG, "null argument");
+    ZK_TRY(use_device(c->device));
+    ZK_TRY(upload_witness(c, witness, canonical));
+    ZK_TRY(enqueue_compute_h(c));
+    ZK_HIP(hipStreamSynchronize(c->s_main));
+    ZK_HIP(hipMemcpy(h_out, c->d_t, 32 * (size_t)c->m, hipMemcpyDeviceToHost));
+    memset(h_out + 4 * (size_t)c->m, 0, 32);
+    return ZK_OK;
+}
+
+template <class C>
+static int msm_host(const uint64_t *bases, const uint64_t *scalars, uint32_t n, uint32_t cbits, int device, uint64_t *out_affine) {
+    if ((n && (!bases || !scalars)) || !out_affine) return fail(ZK_ERR_ARG, "null argument");
+    ZK_TRY(use_device(device));
+    typename C::Affine *d_bases = nullptr; fe *d_scalars = nullptr;
+    MsmWork<C> work;
+    int rc = dev_upload(&d_bases, (const typename C::Affine *)bases, n);
+    if (rc == ZK_OK) rc = dev_upload(&d_scalars, (const fe *)scalars, n);
+    if (rc == ZK_OK) rc = work.alloc(n, cbits);
+    if (rc == ZK_OK) rc = work.enqueue(d_bases, d_scalars, nullptr, n, 0, nullptr);
+    if (rc == ZK_OK && hipDeviceSynchronize() != hipSuccess) rc = fail(ZK_ERR_HIP, "MSM kernels failed");
+    if (rc == ZK_OK) {
+        typename C::Affine a = C::to_affine(work.finish());
+        memcpy(out_affine, &a, sizeof(a));
+    }
+    work.release();
+    if (d_bases) hipFree(d_bases);
+    if (d_scalars) hipFree(d_scalars);
+    return rc;
+}
+extern "C" int zk_msm_g1(const uint64_t *bases, const uint64_t *scalars, uint32_t n, uint32_t c, int device, uint64_t out[8]) {
+    return msm_host<G1>(bases, scalars, n, c, device, out);
+}
+extern "C" int zk_msm_g2(const uint64_t *bases, const uint64_t *scalars, uint32_t n, uint32_t c, int device, uint64_t out[16]) {
+    return msm_host<G2>(bases, scalars, n, c, device, out);
+}
+
+extern "C" int zk_field_mul(const uint64_t *a, const uint64_t *b, uint64_t *out, uint32_t n, int field, int device) {
+    if (!a || !b || !out) return fail(ZK_ERR_ARG, "null argument");
+    ZK_TRY(use_device(device));
+    fe *da = nullptr, *db = nullptr, *dout = nullptr;
+    int rc = dev_upload(&da, (const fe *)a, n);
+    if (rc == ZK_OK) rc = dev_upload(&db, (const fe *)b, n);
+    if (rc == ZK_OK && hipMalloc(&dout, 32 * (size_t)(n ? n : 1)) != hipSuccess) rc = ZK_ERR_NOMEM;
+    if (rc == ZK_OK && n) { ZK_LAUNCH(k_field_mul, zk_div_up(n, 256), 256, nullptr, (const fe *)da, (const fe *)db, dout, n, field); }
+    if (rc == ZK_OK && hipDeviceSynchronize() != hipSuccess) rc = fail(ZK_ERR_HIP, "kernel failed");
+    if (rc == ZK_OK && n && hipMemcpy(out, dout, 32 * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) rc = ZK_ERR_HIP;
+    if (da) hipFree(da);
+    if (db) hipFree(db);
+    if (dout) hipFree(dout);
+    return rc;
+}

@@ -1,0 +1,298 @@
+"""Host-side binding of libzkhip.so (C ABI: include/zkhip.h) for tests/ and bench.py.
+
+The names mirror the reference's proving API (src/stubs.hpp:18-21, src/stubs.cpp:36-75):
+
+    load_proving_key(path)            -> ProvingKey        ethsnarks::load_proving_key
+    ProverContext(pk, r1cs, config)   -> context           ProverContext<ppT> + get_domain
+    prove(ctx, witness)               -> proof JSON str    ethsnarks::prove
+    stub_prove_from_pb(r1cs, w, path) -> proof JSON str    upstream wrapper used by src/pinocchio/main.cpp:41
+
+The reference itself is C++; the C++ adapter with the same signatures lives in
+include/ethsnarks_hip/stubs.hpp.  This module adds nothing to the data path: it passes numpy buffers
+to the C ABI.  It fails loudly when the HIP library is missing -- there is no CPU fallback.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_u64p = C.POINTER(C.c_uint64)
+_u32p = C.POINTER(C.c_uint32)
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libzkhip.so")
+
+
+class ZkError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("zkhip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class ZkCSR(C.Structure):
+    _fields_ = [("n_rows", C.c_uint32), ("row_ptr", _u32p), ("col", _u32p), ("coeff", _u64p)]
+
+
+class ZkConfig(C.Structure):
+    """libsnark::Config (src/prover_config.hpp:8-35) reduced to what a GPU prover consumes."""
+    _fields_ = [("multi_exp_c", C.c_uint32), ("device", C.c_uint32), ("shard_rank", C.c_uint32), ("shard_count", C.c_uint32)]
+
+
+class ZkProof(C.Structure):
+    _fields_ = [(n, C.c_uint64 * 4) for n in
+                ("a_x", "a_y", "b_x_c0", "b_x_c1", "b_y_c0", "b_y_c1", "c_x", "c_y")] + \
+               [("a_inf", C.c_uint32), ("b_inf", C.c_uint32), ("c_inf", C.c_uint32), ("_pad", C.c_uint32)]
+
+
+class ZkPartials(C.Structure):
+    _fields_ = [("At", C.c_uint64 * 16), ("Bt", C.c_uint64 * 32), ("Ht", C.c_uint64 * 16), ("Lt", C.c_uint64 * 16)]
+
+
+class ZkTimings(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("h2d_witness", "compute_h", "a_query", "b_query", "h_query", "l_query", "gpu_total", "host_finish")]
+
+    def as_dict(self):
+        return {n: float(getattr(self, n)) for n, _ in self._fields_}
+
+
+EXPORTS = [
+    "zk_version", "zk_strerror", "zk_last_error", "zk_device_count",
+    "zk_pk_load_raw", "zk_pk_save_raw", "zk_pk_from_parts", "zk_pk_sizes", "zk_pk_part", "zk_pk_free",
+    "zk_domain_size", "zk_ctx_create", "zk_ctx_destroy",
+    "zk_prove", "zk_prove_timed", "zk_prove_partial", "zk_prove_combine", "zk_proof_to_json",
+    "zk_ntt", "zk_witness_map", "zk_msm_g1", "zk_msm_g2", "zk_field_mul",
+]
+
+_lib = None
+_lib_path_loaded = None
+
+
+def load_library(path=None):
+    """Load libzkhip.so (or an explicitly named build of the same ABI).  Raises if it is missing."""
+    global _lib, _lib_path_loaded
+    path = path or LIB_PATH
+    if _lib is not None and _lib_path_loaded == path:
+        return _lib
+    if not os.path.exists(path):
+        raise ImportError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950). There is no CPU fallback." % path)
+    L = C.CDLL(path)
+    for n in ("zk_version", "zk_strerror", "zk_last_error"):
+        getattr(L, n).restype = C.c_char_p
+    L.zk_pk_part.restype = C.c_void_p
+    L.zk_domain_size.restype = C.c_uint32
+    _lib, _lib_path_loaded = L, path
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        L = load_library(_lib_path_loaded)
+        raise ZkError(rc, (L.zk_last_error() or L.zk_strerror(rc)).decode())
+
+
+def _p64(a):
+    return a.ctypes.data_as(_u64p)
+
+
+def _p32(a):
+    return a.ctypes.data_as(_u32p)
+
+
+def _c64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    return a if shape is None else a.reshape(shape)
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = load_library(_lib_path_loaded).zk_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+class ProvingKey:
+    """ethsnarks::ProvingKeyT = r1cs_gg_ppzksnark_zok_proving_key_nozk (hpp:171-274): host object."""
+
+    def __init__(self, handle):
+        self._h = handle
+        s = (C.c_uint32 * 6)()
+        _check(_lib.zk_pk_sizes(handle, s))
+        self.a_domain, self.nA, self.b_domain, self.nB, self.nH, self.nL = list(s)
+
+    @staticmethod
+    def from_parts(alpha_g1, beta_g1, beta_g2, delta_g1, delta_g2, a_domain, a_idx, a_val, b_domain, b_idx, b_val, H, L):
+        lib = load_library(_lib_path_loaded)
+        a_idx = np.ascontiguousarray(a_idx, dtype=np.uint32); b_idx = np.ascontiguousarray(b_idx, dtype=np.uint32)
+        a_val = _c64(a_val); b_val = _c64(b_val); H = _c64(H); L = _c64(L)
+        h = C.c_void_p()
+        _check(lib.zk_pk_from_parts(_p64(_c64(alpha_g1)), _p64(_c64(beta_g1)), _p64(_c64(beta_g2)), _p64(_c64(delta_g1)), _p64(_c64(delta_g2)),
+                                    C.c_uint32(a_domain), C.c_uint32(len(a_idx)), _p32(a_idx), _p64(a_val),
+                                    C.c_uint32(b_domain), C.c_uint32(len(b_idx)), _p32(b_idx), _p64(b_val),
+                                    C.c_uint32(H.size // 8), _p64(H), C.c_uint32(L.size // 8), _p64(L), C.byref(h)))
+        return ProvingKey(h)
+
+    def part(self, which, shape, dtype=np.uint64):
+        n = int(np.prod(shape))
+        if n == 0:
+            return np.zeros(shape, dtype=dtype)
+        p = _lib.zk_pk_part(self._h, which)
+        ct = (C.c_uint64 if dtype == np.uint64 else C.c_uint32) * n
+        return np.frombuffer(ct.from_address(p), dtype=dtype).reshape(shape).copy()
+
+    def parts(self):
+        return dict(alpha_g1=self.part(0, (8,)), beta_g1=self.part(1, (8,)), beta_g2=self.part(2, (16,)),
+                    delta_g1=self.part(3, (8,)), delta_g2=self.part(4, (16,)),
+                    a_domain=self.a_domain, a_idx=self.part(5, (self.nA,), np.uint32), a_val=self.part(6, (self.nA, 8)),
+                    b_domain=self.b_domain, b_idx=self.part(7, (self.nB,), np.uint32), b_val=self.part(8, (self.nB, 16)),
+                    H=self.part(9, (self.nH, 8)), L=self.part(10, (self.nL, 8)))
+
+    def save_raw(self, path, codec=0):
+        """writeToFile<ProvingKeyT> (src/utils.hpp:166-173)."""
+        _check(_lib.zk_pk_save_raw(self._h, os.fsencode(path), codec))
+
+    def close(self):
+        if self._h is not None and _lib is not None:
+            _lib.zk_pk_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def load_proving_key(pk_file, codec=0):
+    """ethsnarks::load_proving_key (src/stubs.cpp:36-39).  A missing file is an error here
+    (the reference asserts, src/utils.hpp:180)."""
+    lib = load_library(_lib_path_loaded)
+    h = C.c_void_p()
+    _check(lib.zk_pk_load_raw(os.fsencode(pk_file), codec, C.byref(h)))
+    return ProvingKey(h)
+
+
+def get_domain_size(r1cs):
+    """size of the domain ethsnarks::get_domain builds (src/stubs.cpp:61-75)."""
+    return int(load_library(_lib_path_loaded).zk_domain_size(C.c_uint32(r1cs.nC), C.c_uint32(r1cs.nIn)))
+
+
+class ProverContext:
+    """ProverContext<ppT> (hpp:279-291) + get_domain: bases and CSR resident in HBM, scratch owned."""
+
+    def __init__(self, pk, r1cs, multi_exp_c=0, device=0, shard_rank=0, shard_count=1):
+        lib = load_library(_lib_path_loaded)
+        self.r1cs = r1cs
+        self._keep = []
+
+        def csr(m):
+            rp = np.ascontiguousarray(m.row_ptr, dtype=np.uint32)
+            co = np.ascontiguousarray(m.col, dtype=np.uint32)
+            cf = _c64(m.coeff)
+            self._keep += [rp, co, cf]
+            return ZkCSR(m.n_rows, _p32(rp), _p32(co), _p64(cf))
+        a, b, c = csr(r1cs.A), csr(r1cs.B), csr(r1cs.C)
+        cfg = ZkConfig(multi_exp_c, device, shard_rank, shard_count)
+        h = C.c_void_p()
+        _check(lib.zk_ctx_create(pk._h, C.byref(a), C.byref(b), C.byref(c), C.c_uint32(r1cs.nC), C.c_uint32(r1cs.nIn),
+                                 C.c_uint32(r1cs.V), C.byref(cfg), C.byref(h)))
+        self._h = h
+        self._keep = []     # the context copied everything it needs
+        self.shard_count = shard_count
+
+    def _w(self, witness):
+        w = _c64(witness)
+        if w.size != 4 * (self.r1cs.V + 1):
+            raise ValueError("witness must have V + 1 = %d elements" % (self.r1cs.V + 1))
+        return w
+
+    def prove_struct(self, witness, canonical=False, timings=False):
+        w = self._w(witness)
+        proof = ZkProof()
+        if timings:
+            t = ZkTimings()
+            _check(_lib.zk_prove_timed(self._h, _p64(w), int(canonical), C.byref(proof), C.byref(t)))
+            return proof, t.as_dict()
+        _check(_lib.zk_prove(self._h, _p64(w), int(canonical), C.byref(proof)))
+        return proof
+
+    def prove_partial(self, witness, canonical=False):
+        w = self._w(witness)
+        part = ZkPartials()
+        _check(_lib.zk_prove_partial(self._h, _p64(w), int(canonical), C.byref(part)))
+        return np.frombuffer(bytes(part), dtype=np.uint64).copy()      # 80 u64 = 640 bytes
+
+    def prove_combine(self, partials):
+        arr = _c64(partials).reshape(-1, 80)
+        proof = ZkProof()
+        _check(_lib.zk_prove_combine(self._h, C.cast(_p64(arr), C.POINTER(ZkPartials)), C.c_uint32(arr.shape[0]), C.byref(proof)))
+        return proof
+
+    def witness_map(self, witness, canonical=False):
+        w = self._w(witness)
+        m = self.r1cs.domain_size
+        h = np.zeros((m + 1, 4), dtype=np.uint64)
+        _check(_lib.zk_witness_map(self._h, _p64(w), int(canonical), _p64(h)))
+        return h
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and _lib is not None:
+            _lib.zk_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def proof_to_json(proof, inputs, canonical=False):
+    """ethsnarks::proof_to_json (src/export.cpp:99-121): exact text."""
+    inputs = _c64(inputs).reshape(-1, 4)
+    n = inputs.shape[0]
+    cap = 2048 + 80 * n
+    buf = C.create_string_buffer(cap)
+    ln = C.c_size_t(0)
+    _check(_lib.zk_proof_to_json(C.byref(proof), _p64(inputs) if n else None, C.c_uint32(n), int(canonical), buf, C.c_size_t(cap), C.byref(ln)))
+    return buf.raw[:ln.value].decode()
+
+
+def prove(ctx, witness, canonical=False):
+    """ethsnarks::prove(ProverContextT&, ProtoboardT&) (src/stubs.cpp:42-47): proof JSON string.
+    `witness` plays pb.values (ONE at index 0); primary input = witness[1..nIn]."""
+    w = _c64(witness).reshape(-1, 4)
+    proof = ctx.prove_struct(w, canonical)
+    return proof_to_json(proof, w[1:1 + ctx.r1cs.nIn], canonical)
+
+
+def stub_prove_from_pb(r1cs, witness, pk_file, **kw):
+    """upstream ethsnarks convenience wrapper still referenced by src/pinocchio/main.cpp:10,41."""
+    pk = load_proving_key(pk_file)
+    ctx = ProverContext(pk, r1cs, **kw)
+    try:
+        return prove(ctx, witness)
+    finally:
+        ctx.close()
+        pk.close()
+
+
+# ---- kernel-level entry points
+def ntt(data, logm, inverse=False, coset=False, device=0):
+    a = _c64(data).copy()
+    _check(load_library(_lib_path_loaded).zk_ntt(_p64(a), C.c_uint32(logm), int(inverse), int(coset), device))
+    return a
+
+
+def msm(bases, scalars, g2=False, c=0, device=0):
+    lib = load_library(_lib_path_loaded)
+    bases = _c64(bases); scalars = _c64(scalars)
+    n = scalars.size // 4
+    out = np.zeros(16 if g2 else 8, dtype=np.uint64)
+    fn = lib.zk_msm_g2 if g2 else lib.zk_msm_g1
+    _check(fn(_p64(bases) if n else None, _p64(scalars) if n else None, C.c_uint32(n), C.c_uint32(c), device, _p64(out)))
+    return out
+
+
+def field_mul(a, b, field="fr", device=0):
+    a = _c64(a); b = _c64(b)
+    out = np.zeros_like(a)
+    _check(load_library(_lib_path_loaded).zk_field_mul(_p64(a), _p64(b), _p64(out), C.c_uint32(a.size // 4), 0 if field == "fr" else 1, device))
+    return out

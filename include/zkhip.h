@@ -1,0 +1,139 @@
+/*
+ * zkhip.h -- C ABI of libzkhip.so, the MI355X (gfx950) Groth16 proving backend for ethsnarks.
+ *
+ * Drop-in boundary for the reference's proving path (citations into zkh2018/ethsnarks):
+ *
+ *   zk_pk_load_raw      <- ethsnarks::load_proving_key(pk_file)              src/stubs.cpp:36-39
+ *                          loadFromFile<ProvingKeyT>                         src/utils.hpp:176-185
+ *                          operator>>(istream&, pk_nozk&)                    r1cs_gg_ppzksnark_zok.tcc:124-143
+ *   zk_pk_save_raw      <- writeToFile<ProvingKeyT> / operator<<             src/utils.hpp:166-173, tcc:108-122
+ *   zk_pk_from_parts    <- r1cs_gg_ppzksnark_zok_proving_key_nozk ctor       r1cs_gg_ppzksnark_zok.hpp:171-233
+ *   zk_ctx_create       <- ProverContext<ppT>(pk) + get_domain(pb, pk, cfg)  hpp:279-291, src/stubs.cpp:61-75
+ *   zk_prove            <- r1cs_gg_ppzksnark_zok_prover(ctx, pb.values)      tcc:451-550 (via prove(), stubs.cpp:42-47)
+ *   zk_proof_to_json    <- proof_to_json(proof, primary_input)               src/export.cpp:99-121
+ *   zk_config           <- libsnark::Config                                   src/prover_config.hpp:8-35
+ *
+ * Plain C types only.  Field elements are 4 x u64 little-endian limbs; "Montgomery" means the
+ * libff::Fp_model<4> in-memory form (value * 2^256 mod p), which is what `pb.values` and the `.raw`
+ * key file contain.  Affine G1 = {x, y} (8 u64), affine G2 = {x.c0, x.c1, y.c0, y.c1} (16 u64); an
+ * all-zero point encodes infinity.  All functions return 0 (ZK_OK) or a positive error code; none
+ * throws or aborts.  zk_last_error() gives a thread-local human-readable message.
+ *
+ * There is NO CPU implementation behind this ABI: every compute entry point needs a HIP device and
+ * fails with ZK_ERR_NODEVICE / ZK_ERR_HIP otherwise.
+ */
+#ifndef ZKHIP_H
+#define ZKHIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZK_OK 0
+#define ZK_ERR_ARG 1       /* null / inconsistent argument */
+#define ZK_ERR_IO 2        /* cannot open / read / write file (reference: assert in utils.hpp:180) */
+#define ZK_ERR_FORMAT 3    /* malformed .raw stream */
+#define ZK_ERR_HIP 4       /* HIP runtime error */
+#define ZK_ERR_NOMEM 5
+#define ZK_ERR_SHAPE 6     /* key does not match the constraint system (DEBUG asserts tcc:477-483) */
+#define ZK_ERR_DEGREE 7    /* H has wrong degree: witness does not satisfy the R1CS (asserts tcc:472-474) */
+#define ZK_ERR_NODEVICE 8
+#define ZK_ERR_BUFFER 9    /* output buffer too small */
+
+#define ZK_CODEC_ALT_BN128 0   /* upstream libff layout; the only codec validated so far */
+
+typedef struct zk_pk zk_pk;
+typedef struct zk_ctx zk_ctx;
+
+typedef struct {
+    uint32_t n_rows;
+    const uint32_t *row_ptr;   /* n_rows + 1 */
+    const uint32_t *col;       /* variable index; 0 is the constant ONE */
+    const uint64_t *coeff;     /* nnz x 4, Montgomery Fr */
+} zk_csr;
+
+/* mirrors libsnark::Config (src/prover_config.hpp:8-35).  CPU-cache knobs of the reference
+ * (num_threads, smt, fft, radixes, prefetch_*, look_ahead) have no meaning on the GPU and are
+ * accepted and ignored by the C++ adapter; what remains: */
+typedef struct {
+    uint32_t multi_exp_c;      /* Pippenger window bits, 0 = auto (Config::multi_exp_c) */
+    uint32_t device;           /* HIP device ordinal */
+    uint32_t shard_rank;       /* MSM base-range sharding: this context owns shard_rank of shard_count */
+    uint32_t shard_count;      /* 0 or 1 = unsharded */
+} zk_config;
+
+/* canonical (non-Montgomery) affine coordinates; *_inf != 0 => point at infinity, printed as (0, 1) */
+typedef struct {
+    uint64_t a_x[4], a_y[4];
+    uint64_t b_x_c0[4], b_x_c1[4], b_y_c0[4], b_y_c1[4];
+    uint64_t c_x[4], c_y[4];
+    uint32_t a_inf, b_inf, c_inf, _pad;
+} zk_proof;
+
+/* per-shard partial results of the four multi-exponentiations, XYZZ coordinates, Montgomery:
+ * At, Ht, Lt: 4 x 4 u64 each (G1); Bt: 4 x 8 u64 (G2)  => 3*128 + 256 = 640 bytes */
+typedef struct {
+    uint64_t At[16], Bt[32], Ht[16], Lt[16];
+} zk_partials;
+
+/* phase times in milliseconds, named after the reference's enter_block labels (tcc:460-542) */
+typedef struct {
+    float h2d_witness;
+    float compute_h;           /* "Compute the polynomial H" */
+    float a_query, b_query, h_query, l_query;   /* GPU time of each multi-exponentiation */
+    float gpu_total;           /* first kernel to last copy */
+    float host_finish;         /* window Horner, final additions, affine conversion */
+} zk_timings;
+
+/* ---- library / device */
+const char *zk_version(void);
+const char *zk_strerror(int code);
+const char *zk_last_error(void);
+int zk_device_count(int *count);
+
+/* ---- proving key (host object; zk_ctx_create uploads it) */
+int zk_pk_load_raw(const char *path, int codec, zk_pk **out);
+int zk_pk_save_raw(const zk_pk *pk, const char *path, int codec);
+int zk_pk_from_parts(const uint64_t *alpha_g1, const uint64_t *beta_g1, const uint64_t *beta_g2,
+                     const uint64_t *delta_g1, const uint64_t *delta_g2,
+                     uint32_t a_domain, uint32_t nA, const uint32_t *a_idx, const uint64_t *a_val,
+                     uint32_t b_domain, uint32_t nB, const uint32_t *b_idx, const uint64_t *b_val,
+                     uint32_t nH, const uint64_t *H, uint32_t nL, const uint64_t *L, zk_pk **out);
+/* sizes[0..5] = A.domain, nA, B.domain, nB, nH, nL */
+int zk_pk_sizes(const zk_pk *pk, uint32_t sizes[6]);
+/* which: 0 alpha_g1 1 beta_g1 2 beta_g2 3 delta_g1 4 delta_g2 5 A.idx 6 A.val 7 B.idx 8 B.val 9 H 10 L */
+const void *zk_pk_part(const zk_pk *pk, int which);
+void zk_pk_free(zk_pk *pk);
+
+/* ---- prover context: uploads bases + CSR once, builds domain tables, owns all scratch.
+ * Borrows nothing after return (pk and CSR may be freed), one context per concurrent prover. */
+uint32_t zk_domain_size(uint32_t nC, uint32_t nIn);                      /* src/stubs.cpp:49-65 */
+int zk_ctx_create(const zk_pk *pk, const zk_csr *A, const zk_csr *B, const zk_csr *C,
+                  uint32_t nC, uint32_t nIn, uint32_t V, const zk_config *cfg, zk_ctx **out);
+void zk_ctx_destroy(zk_ctx *ctx);
+
+/* witness: (V + 1) x 4 u64, ONE at index 0 (pb.values layout), Montgomery unless canonical != 0 */
+int zk_prove(zk_ctx *ctx, const uint64_t *witness, int canonical, zk_proof *out);
+int zk_prove_timed(zk_ctx *ctx, const uint64_t *witness, int canonical, zk_proof *out, zk_timings *t);
+/* sharded contexts: each rank computes its partial sums; after exchanging them (e.g. an RCCL
+ * all-gather of the 640-byte structs), any rank folds them in rank order and finishes the proof */
+int zk_prove_partial(zk_ctx *ctx, const uint64_t *witness, int canonical, zk_partials *out);
+int zk_prove_combine(const zk_ctx *ctx, const zk_partials *parts, uint32_t count, zk_proof *out);
+
+/* inputs: nIn Fr elements = witness[1..nIn] (Montgomery unless canonical); returns the JSON length
+ * (excluding NUL) through *len; ZK_ERR_BUFFER if cap is too small (len still set) */
+int zk_proof_to_json(const zk_proof *proof, const uint64_t *inputs, uint32_t nIn, int canonical,
+                     char *buf, size_t cap, size_t *len);
+
+/* ---- kernel-level entry points (parity tests / micro-benchmarks); host buffers in and out */
+int zk_ntt(uint64_t *data, uint32_t logm, int inverse, int coset, int device);
+int zk_witness_map(zk_ctx *ctx, const uint64_t *witness, int canonical, uint64_t *h_out /* (m+1) x 4 */);
+int zk_msm_g1(const uint64_t *bases, const uint64_t *scalars, uint32_t n, uint32_t c, int device, uint64_t out_affine[8]);
+int zk_msm_g2(const uint64_t *bases, const uint64_t *scalars, uint32_t n, uint32_t c, int device, uint64_t out_affine[16]);
+int zk_field_mul(const uint64_t *a, const uint64_t *b, uint64_t *out, uint32_t n, int field /* 0 Fr, 1 Fq */, int device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,111 @@
+// tests/emul/hip_emul.h -- TEST INFRASTRUCTURE ONLY.
+//
+// A minimal single-process stand-in for the HIP runtime so that the kernel *logic* in
+// ethsnarks_amd/csrc (indexing, scans, bucket bookkeeping, barrier placement) can be exercised by
+// `pytest -m "not gpu"` in a container that has no GPU.  The same kernel sources are compiled with
+// g++ -DZK_EMUL into tests/emul/libzkhip_emul.so; a "launch" runs the blocks one after another, the
+// threads of a block either sequentially (kernels without block barriers) or as real threads with a
+// barrier (kernels that call __syncthreads()).  The product (libzkhip.so) never sees this file, the
+// Python package never loads the emulation library, and nothing here is ever timed or shipped.
+#pragma once
+#include <atomic>
+#include <condition_variable>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __shared__ static
+#define __launch_bounds__(...)
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+inline thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
+
+namespace zk_emul {
+struct Barrier {
+    std::mutex m; std::condition_variable cv; unsigned n = 0, waiting = 0, gen = 0;
+    void wait() {
+        std::unique_lock<std::mutex> lk(m);
+        unsigned g = gen;
+        if (++waiting == n) { waiting = 0; gen++; cv.notify_all(); }
+        else cv.wait(lk, [&] { return gen != g; });
+    }
+};
+inline Barrier *g_barrier = nullptr;
+
+template <class Body>
+void launch(bool needs_sync, dim3 grid, dim3 block, Body body) {
+    for (unsigned bx = 0; bx < grid.x; bx++) {
+        if (!needs_sync) {
+            for (unsigned tx = 0; tx < block.x; tx++) {
+                threadIdx = dim3(tx); blockIdx = dim3(bx); blockDim = block; gridDim = grid;
+                body();
+            }
+        } else {
+            Barrier bar; bar.n = block.x; g_barrier = &bar;
+            std::vector<std::thread> th;
+            for (unsigned tx = 0; tx < block.x; tx++)
+                th.emplace_back([&, tx] {
+                    threadIdx = dim3(tx); blockIdx = dim3(bx); blockDim = block; gridDim = grid;
+                    body();
+                });
+            for (auto &t : th) t.join();
+            g_barrier = nullptr;
+        }
+    }
+}
+}  // namespace zk_emul
+
+inline void __syncthreads() { if (zk_emul::g_barrier) zk_emul::g_barrier->wait(); }
+inline unsigned atomicAdd(unsigned *p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+inline unsigned atomicMax(unsigned *p, unsigned v) {
+    unsigned old = *p;
+    while (old < v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {}
+    return old;
+}
+
+// ---- runtime API subset (synchronous)
+typedef int hipError_t;
+typedef void *hipStream_t;
+typedef struct { double t; } *hipEvent_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNoDevice = 100 };
+enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyHostToHost };
+enum { hipStreamNonBlocking = 1, hipHostMallocDefault = 0 };
+inline const char *hipGetErrorString(hipError_t e) { return e ? "emul error" : "ok"; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+template <class T> hipError_t hipMalloc(T **p, size_t n) { *p = (T *)calloc(n ? n : 1, 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
+template <class T> hipError_t hipHostMalloc(T **p, size_t n, unsigned = 0) { *p = (T *)calloc(n ? n : 1, 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
+inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { if (n) memmove(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind k, hipStream_t) { return hipMemcpy(d, s, n, k); }
+inline hipError_t hipMemset(void *d, int v, size_t n) { if (n) memset(d, v, n); return hipSuccess; }
+inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { return hipMemset(d, v, n); }
+inline hipError_t hipStreamCreate(hipStream_t *s) { *s = nullptr; return hipSuccess; }
+inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = nullptr; return hipSuccess; }
+inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipEventCreate(hipEvent_t *e) { *e = (hipEvent_t)calloc(1, sizeof(**e)); return hipSuccess; }
+inline hipError_t hipEventDestroy(hipEvent_t e) { free(e); return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) {
+    struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); e->t = ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; return hipSuccess;
+}
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t - a->t); return hipSuccess; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned = 0) { return hipSuccess; }

@@ -1,0 +1,51 @@
+"""The C-ABI library loads and exports every symbol include/zkhip.h declares; without a GPU every
+compute entry point fails loudly (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+import numpy as np
+import pytest
+from conftest import ROOT, gpu_available
+
+LIB = os.path.join(ROOT, "ethsnarks_amd", "libzkhip.so")
+
+
+def declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "zkhip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(zk_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_header_symbols_are_bound_in_python():
+    from ethsnarks_amd import prover
+    assert sorted(prover.EXPORTS) == declared_symbols()
+
+
+@pytest.mark.skipif(not os.path.exists(LIB), reason="libzkhip.so not built (run __graft_entry__.build())")
+def test_library_exports_every_declared_symbol():
+    L = C.CDLL(LIB)
+    for name in declared_symbols():
+        assert hasattr(L, name), name
+    L.zk_version.restype = C.c_char_p
+    assert b"gfx950" in L.zk_version()
+
+
+@pytest.mark.skipif(not os.path.exists(LIB) or gpu_available(), reason="needs the built library and NO gpu")
+def test_compute_fails_loudly_without_device():
+    from ethsnarks_amd import prover
+    prover._lib = None; prover._lib_path_loaded = None
+    prover.load_library()
+    a = np.zeros((4, 4), dtype=np.uint64)
+    with pytest.raises(prover.ZkError) as e:
+        prover.field_mul(a, a)
+    assert e.value.code in (4, 8)
+    with pytest.raises(prover.ZkError):
+        prover.ntt(a, 2)
+    prover._lib = None; prover._lib_path_loaded = None
+
+
+def test_missing_library_is_an_import_error(tmp_path):
+    from ethsnarks_amd import prover
+    prover._lib = None; prover._lib_path_loaded = None
+    with pytest.raises(ImportError):
+        prover.load_library(str(tmp_path / "libzkhip.so"))

@@ -1,0 +1,124 @@
+"""Kernel-logic tests without a GPU: the HIP sources compiled against tests/emul/hip_emul.h
+(libzkhip_emul.so, CPU stand-in, test infrastructure only) are checked against the oracle.
+The same checks run on the real device in test_gpu_parity.py."""
+import json
+import numpy as np
+import pytest
+from ethsnarks_amd import r1cs as R, fields as F
+from helpers import golden_cases, build_case, rand_scalars
+
+
+@pytest.fixture(scope="module")
+def zk(emul):
+    from ethsnarks_amd import prover
+    prover._lib = None
+    prover._lib_path_loaded = None
+    prover.load_library(emul)
+    assert b"EMULATION" in prover._lib.zk_version()
+    yield prover
+    prover._lib = None
+    prover._lib_path_loaded = None
+
+
+def test_field_mul(zk, oracle):
+    a = F.fr_to_mont(rand_scalars(70, 1)); b = F.fr_to_mont(rand_scalars(70, 2))
+    o = np.zeros_like(a)
+    oracle.lib().orc_fr_mul(oracle._p64(o), oracle._p64(a), oracle._p64(b), 70)
+    assert np.array_equal(zk.field_mul(a, b, "fr"), o)
+    oracle.lib().orc_fq_mul(oracle._p64(o), oracle._p64(a), oracle._p64(b), 70)
+    assert np.array_equal(zk.field_mul(a, b, "fq"), o)
+
+
+@pytest.mark.parametrize("logm", [0, 1, 2, 5, 11, 12, 14])
+def test_ntt(zk, oracle, logm):
+    x = F.fr_to_mont(rand_scalars(1 << logm, logm))
+    for inv in (False, True):
+        for coset in (False, True):
+            assert np.array_equal(zk.ntt(x, logm, inv, coset), oracle.ntt(x, logm, inv, coset))
+
+
+@pytest.mark.parametrize("g2", [False, True])
+@pytest.mark.parametrize("n,c", [(0, 0), (1, 0), (7, 0), (300, 4), (1000, 0), (1000, 9)])
+def test_msm(zk, oracle, g2, n, c):
+    sc = rand_scalars(n, n + 1, ones_every=5, zeros_every=7)
+    if n > 20:
+        sc[11] = F.FR - 1; sc[12] = 2; sc[13] = 1 << 253
+    s = F.fr_to_mont(sc) if n else np.zeros((0, 4), dtype=np.uint64)
+    bases = oracle.batch_mul(F.fr_to_mont(rand_scalars(n, 99)), g2=g2) if n else np.zeros((0, 16 if g2 else 8), dtype=np.uint64)
+    if n > 30:
+        bases[20] = 0; bases[21] = bases[22]
+    assert np.array_equal(zk.msm(bases, s, g2=g2, c=c), oracle.msm(bases, s, g2=g2))
+
+
+def test_msm_heavy_bucket(zk, oracle):
+    """thousands of equal scalars (the scalar==1 partition of *_with_mixed_addition): workgroup path"""
+    n = 3600
+    s = F.fr_to_mont([1] * 3000 + [77] * 500 + rand_scalars(100, 5))
+    bases = oracle.batch_mul(F.fr_to_mont(rand_scalars(n, 6)))
+    assert np.array_equal(zk.msm(bases, s, c=6), oracle.msm(bases, s))
+
+
+def test_msm_all_cancel(zk, oracle):
+    """P and -P with equal scalars, and P + P: exceptional cases of the mixed addition"""
+    pts = oracle.batch_mul(F.fr_to_mont([5, 5, 9]))
+    neg = pts[0].copy()
+    y = F.fq_from_mont(neg[4:8].reshape(1, 4))[0]
+    neg[4:8] = F.fq_to_mont([(-y) % F.FQ])[0]
+    bases = np.stack([pts[0], neg, pts[2], pts[2]])
+    s = F.fr_to_mont([3, 3, 4, 4])
+    got = zk.msm(bases, s, c=3)
+    assert np.array_equal(got, oracle.msm(bases, s, naive=True))
+    s0 = F.fr_to_mont([3, 3, 0, 0])
+    assert (zk.msm(bases, s0, c=3) == 0).all()          # infinity
+
+
+@pytest.mark.parametrize("case", golden_cases()[:3], ids=lambda c: c["name"])
+def test_prove_golden(zk, oracle, case):
+    r, w, toxic = build_case(case)
+    pk_o, _ = oracle.keygen(r, toxic=toxic)
+    pk = zk.ProvingKey.from_parts(**pk_o.parts())
+    ctx = zk.ProverContext(pk, r)
+    assert zk.prove(ctx, F.fr_to_mont(w)) == case["proof_json"]
+    assert zk.prove(ctx, F.ints_to_limbs(w), canonical=True) == case["proof_json"]
+    ctx.close()
+
+
+def test_prove_chain_long_rows_and_sharding(zk, oracle, tmp_path):
+    r, w = R.synthetic_chain(510, 1)                    # last row: 1022 terms -> long-row path
+    wm = F.fr_to_mont(w)
+    pk_o, _ = oracle.keygen(r, seed=3)
+    expect, _ = oracle.prove(pk_o, r, wm)
+    path = str(tmp_path / "pk.raw")
+    pk_o.write_raw(path)
+    pk = zk.load_proving_key(path)
+    ctx = zk.ProverContext(pk, r)
+    assert np.array_equal(ctx.witness_map(wm), oracle.witness_map(r, wm))
+    assert zk.prove(ctx, wm) == expect
+    assert zk.stub_prove_from_pb(r, wm, path) == expect
+    parts = [zk.ProverContext(pk, r, shard_rank=k, shard_count=3).prove_partial(wm) for k in range(3)]
+    assert zk.proof_to_json(ctx.prove_combine(np.stack(parts)), wm[1:2]) == expect
+    out = str(tmp_path / "pk2.raw")
+    pk.save_raw(out)
+    assert open(out, "rb").read() == open(path, "rb").read()
+
+
+def test_errors(zk, oracle, tmp_path):
+    r, w = R.random_r1cs(12, 1, seed=2)
+    pk_o, _ = oracle.keygen(r, seed=3)
+    pk = zk.ProvingKey.from_parts(**pk_o.parts())
+    ctx = zk.ProverContext(pk, r)
+    bad = list(w); bad[-4] = (bad[-4] + 1) % F.FR
+    with pytest.raises(zk.ZkError) as e:
+        zk.prove(ctx, F.fr_to_mont(bad))
+    assert e.value.code == 7                                   # ZK_ERR_DEGREE
+    r2, _ = R.random_r1cs(20, 1, seed=2)
+    with pytest.raises(zk.ZkError) as e:
+        zk.ProverContext(pk, r2)
+    assert e.value.code == 6                                   # ZK_ERR_SHAPE
+    with pytest.raises(zk.ZkError) as e:
+        zk.load_proving_key(str(tmp_path / "nope.raw"))
+    assert e.value.code == 2                                   # ZK_ERR_IO
+    p = tmp_path / "junk.raw"; p.write_bytes(b"0" + b"\x01" * 40)
+    with pytest.raises(zk.ZkError) as e:
+        zk.load_proving_key(str(p))
+    assert e.value.code == 3                                   # ZK_ERR_FORMAT

@@ -1,0 +1,149 @@
+"""GPU parity tests: libzkhip.so (HIP, gfx950) through its C ABI vs the CPU oracle on the same
+seeded inputs; bit-exact (integer arithmetic, no tolerance).  Full-size cases use size-independent
+properties (round trips, permutation / split invariance)."""
+import json
+import numpy as np
+import pytest
+from ethsnarks_amd import r1cs as R, fields as F
+from helpers import golden_cases, build_case, rand_scalars, tiled_bases
+
+pytestmark = pytest.mark.gpu
+
+
+def test_native_library_is_loaded(hip):
+    assert hip._lib_path_loaded.endswith("ethsnarks_amd/libzkhip.so")
+    assert hip.device_count() >= 1
+
+
+def test_field_mul(hip, oracle):
+    n = 5000
+    a = F.fr_to_mont(rand_scalars(n, 1)); b = F.fr_to_mont(rand_scalars(n, 2))
+    a[0] = 0; b[1] = 0; a[2] = F.ints_to_limbs([F.FR - 1])[0]; b[2] = a[2]
+    o = np.zeros_like(a)
+    oracle.lib().orc_fr_mul(oracle._p64(o), oracle._p64(a), oracle._p64(b), n)
+    assert np.array_equal(hip.field_mul(a, b, "fr"), o)
+    a[2] = F.ints_to_limbs([F.FQ - 1])[0]; b[2] = a[2]
+    oracle.lib().orc_fq_mul(oracle._p64(o), oracle._p64(a), oracle._p64(b), n)
+    assert np.array_equal(hip.field_mul(a, b, "fq"), o)
+
+
+@pytest.mark.parametrize("logm", [0, 1, 4, 10, 11, 12, 15, 18, 20])
+def test_ntt_vs_oracle(hip, oracle, logm):
+    rng = np.random.default_rng(logm)
+    x = rng.integers(0, 1 << 62, size=(1 << logm, 4), dtype=np.uint64)
+    x[:, 3] &= (1 << 59) - 1                        # < 2^251 < r: valid reduced representatives
+    for inv in (False, True):
+        for coset in (False, True):
+            assert np.array_equal(hip.ntt(x, logm, inv, coset), oracle.ntt(x, logm, inv, coset)), (logm, inv, coset)
+
+
+def test_ntt_roundtrip_full_size(hip):
+    logm = 22
+    rng = np.random.default_rng(7)
+    x = rng.integers(0, 1 << 62, size=(1 << logm, 4), dtype=np.uint64)
+    x[:, 3] &= (1 << 59) - 1
+    y = hip.ntt(x, logm, False, True)
+    assert not np.array_equal(x, y)
+    assert np.array_equal(hip.ntt(y, logm, True, True), x)
+
+
+@pytest.mark.parametrize("g2", [False, True], ids=["G1", "G2"])
+@pytest.mark.parametrize("n,c", [(0, 0), (1, 0), (33, 0), (1000, 0), (1000, 11), (20000, 0), (1 << 16, 0)])
+def test_msm_vs_oracle(hip, oracle, g2, n, c):
+    sc = rand_scalars(n, n + 1, ones_every=5, zeros_every=7)
+    if n > 20:
+        sc[11] = F.FR - 1; sc[12] = 2; sc[13] = 1 << 253
+    s = F.fr_to_mont(sc) if n else np.zeros((0, 4), dtype=np.uint64)
+    bases = tiled_bases(oracle, n, g2=g2, distinct=4096)
+    if n > 30:
+        bases[20] = 0; bases[21] = bases[22]
+    assert np.array_equal(hip.msm(bases, s, g2=g2, c=c), oracle.msm(bases, s, g2=g2))
+
+
+def test_msm_heavy_buckets(hip, oracle):
+    n = 40000
+    s = F.fr_to_mont([1] * 30000 + [77] * 5000 + rand_scalars(5000, 5))
+    bases = tiled_bases(oracle, n, distinct=4096)
+    assert np.array_equal(hip.msm(bases, s), oracle.msm(bases, s))
+    assert np.array_equal(hip.msm(bases, s, c=6), oracle.msm(bases, s))
+
+
+def test_msm_exceptional_cases(hip, oracle):
+    pts = oracle.batch_mul(F.fr_to_mont([5, 5, 9]))
+    neg = pts[0].copy()
+    y = F.fq_from_mont(neg[4:8].reshape(1, 4))[0]
+    neg[4:8] = F.fq_to_mont([(-y) % F.FQ])[0]
+    bases = np.stack([pts[0], neg, pts[2], pts[2]])
+    s = F.fr_to_mont([3, 3, 4, 4])
+    assert np.array_equal(hip.msm(bases, s, c=3), oracle.msm(bases, s, naive=True))
+    assert (hip.msm(bases, F.fr_to_mont([3, 3, 0, 0]), c=3) == 0).all()
+
+
+def test_msm_full_size_properties(hip, oracle):
+    """2^20 points: result is invariant under a permutation of the (base, scalar) pairs and equals the
+    oracle on the same data (the oracle takes a few seconds at this size with 16 threads)."""
+    n = 1 << 20
+    rng = np.random.default_rng(3)
+    s = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64); s[:, 3] &= (1 << 59) - 1
+    bases = tiled_bases(oracle, n, distinct=8192)
+    r1 = hip.msm(bases, s)
+    perm = rng.permutation(n)
+    assert np.array_equal(hip.msm(bases[perm], s[perm]), r1)
+    assert np.array_equal(r1, oracle.msm(bases, s))
+
+
+@pytest.mark.parametrize("case", golden_cases(), ids=lambda c: c["name"])
+def test_prove_golden_vectors(hip, oracle, case):
+    r, w, toxic = build_case(case)
+    pk_o, _ = oracle.keygen(r, toxic=toxic)
+    pk = hip.ProvingKey.from_parts(**pk_o.parts())
+    ctx = hip.ProverContext(pk, r)
+    assert hip.prove(ctx, F.fr_to_mont(w)) == case["proof_json"]
+    assert hip.prove(ctx, F.ints_to_limbs(w), canonical=True) == case["proof_json"]
+    ctx.close()
+
+
+@pytest.mark.parametrize("logm", [9, 12, 14])
+def test_prove_chain_vs_oracle(hip, oracle, logm, tmp_path):
+    r, w = R.synthetic_chain((1 << logm) - 2, 1)
+    wm = F.fr_to_mont(w)
+    pk_o, vk_o = oracle.keygen(r, seed=logm)
+    expect, _ = oracle.prove(pk_o, r, wm)
+    path = str(tmp_path / "pk.raw")
+    pk_o.write_raw(path)
+    pk = hip.load_proving_key(path)                     # the .raw reader is on the measured path's boundary
+    ctx = hip.ProverContext(pk, r)
+    assert np.array_equal(ctx.witness_map(wm), oracle.witness_map(r, wm))
+    got = hip.prove(ctx, wm)
+    assert got == expect
+    assert hip.prove(ctx, wm) == expect                 # context reuse (ProverContext scratch, hpp:286-289)
+    parts = [hip.ProverContext(pk, r, shard_rank=k, shard_count=4).prove_partial(wm) for k in range(4)]
+    assert hip.proof_to_json(ctx.prove_combine(np.stack(parts)), wm[1:2]) == expect
+    if logm == 9:
+        import pyref
+        assert pyref.verify(json.loads(vk_o.to_json()), json.loads(got))
+
+
+def test_prove_random_circuits_vs_oracle(hip, oracle):
+    for nC, nIn, small in ((50, 2, False), (300, 1, True), (3000, 5, False)):
+        r, w = R.random_r1cs(nC, nIn, seed=nC, small_values=small)
+        wm = F.fr_to_mont(w)
+        pk_o, _ = oracle.keygen(r, seed=nC)
+        pk = hip.ProvingKey.from_parts(**pk_o.parts())
+        ctx = hip.ProverContext(pk, r)
+        expect, _ = oracle.prove(pk_o, r, wm)
+        assert hip.prove(ctx, wm) == expect
+
+
+def test_errors(hip, oracle, tmp_path):
+    r, w = R.random_r1cs(12, 1, seed=2)
+    pk_o, _ = oracle.keygen(r, seed=3)
+    pk = hip.ProvingKey.from_parts(**pk_o.parts())
+    ctx = hip.ProverContext(pk, r)
+    bad = list(w); bad[-4] = (bad[-4] + 1) % F.FR
+    with pytest.raises(hip.ZkError) as e:
+        hip.prove(ctx, F.fr_to_mont(bad))
+    assert e.value.code == 7
+    with pytest.raises(hip.ZkError) as e:
+        hip.load_proving_key(str(tmp_path / "nope.raw"))
+    assert e.value.code == 2
