@@ -13,11 +13,13 @@
 // extended Jacobian "XYZZ" coordinates (x = X/ZZ, y = Y/ZZZ; ZZ = 0 is infinity): mixed addition is
 // 8M + 2S with no inversion, which is what bucket accumulation wants.
 #pragma once
+#include "common.hpp"
 #include <stdint.h>
 
 #ifndef ZK_HD
 #define ZK_HD __host__ __device__ __forceinline__
 #endif
+#define ZK_HD_NOINLINE __host__ __device__ __attribute__((noinline))
 
 namespace zk {
 
@@ -205,6 +207,7 @@ struct Fq2 {
 template <class F>
 struct Curve {
     typedef typename F::elem E;
+    static constexpr int WAVES_PER_SIMD = sizeof(E) > 32 ? 2 : 4;   // VGPR budget: 256 (G2) / 128 (G1)
     struct alignas(16) Affine { E x, y; };
     struct alignas(16) XYZZ { E X, Y, ZZ, ZZZ; };
 
@@ -241,6 +244,10 @@ struct Curve {
         r.ZZ = F::mul(V, p.ZZ); r.ZZZ = F::mul(W, p.ZZZ);
         return r;
     }
+    // the doubling branches of madd/add are taken only when both operands are the same point: keep
+    // them out of line so the hot loop's code (and its register allocation) stays small
+    static ZK_HD_NOINLINE XYZZ dbl_affine_slow(const Affine &p) { return dbl_affine(p); }
+    static ZK_HD_NOINLINE XYZZ dbl_slow(const XYZZ &p) { return dbl(p); }
     // p + q, q affine (madd-2008-s); all exceptional cases handled -- bit-exactness needs them
     static ZK_HD XYZZ madd(const XYZZ &p, const Affine &q) {
         if (is_inf(q)) return p;
@@ -248,7 +255,7 @@ struct Curve {
         E U2 = F::mul(q.x, p.ZZ), S2 = F::mul(q.y, p.ZZZ);
         E Pd = F::sub(U2, p.X), R = F::sub(S2, p.Y);
         if (F::is_zero(Pd)) {
-            if (F::is_zero(R)) return dbl_affine(q);
+            if (F::is_zero(R)) return dbl_affine_slow(q);
             return infinity();
         }
         E PP = F::sqr(Pd), PPP = F::mul(Pd, PP), Q = F::mul(p.X, PP);
@@ -266,7 +273,7 @@ struct Curve {
         E S1 = F::mul(p.Y, q.ZZZ), S2 = F::mul(q.Y, p.ZZZ);
         E Pd = F::sub(U2, U1), R = F::sub(S2, S1);
         if (F::is_zero(Pd)) {
-            if (F::is_zero(R)) return dbl(p);
+            if (F::is_zero(R)) return dbl_slow(p);
             return infinity();
         }
         E PP = F::sqr(Pd), PPP = F::mul(Pd, PP), Q = F::mul(U1, PP);
@@ -279,7 +286,8 @@ struct Curve {
     // k * p for a small non-negative integer k (bucket-offset weighting), MSB-first double-and-add
     static ZK_HD XYZZ mul_small(const XYZZ &p, uint32_t k) {
         XYZZ acc = infinity();
-        for (int i = 31; i >= 0; i--) {
+        if (!k) return acc;
+        for (int i = 31 - __builtin_clz(k); i >= 0; i--) {
             acc = dbl(acc);
             if ((k >> i) & 1) acc = add(acc, p);
         }

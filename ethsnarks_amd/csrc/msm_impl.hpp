@@ -1,0 +1,237 @@
+// msm_impl.hpp -- kernels and launch code of the multi-scalar multiplication (see msm.hpp for the
+// schedule and the reference call sites).  Included only by msm_g1.cpp / msm_g2.cpp, which instantiate
+// MsmWork<G1> / MsmWork<G2> so that the two curve instantiations compile in parallel.
+#pragma once
+#include "msm.hpp"
+
+namespace zk {
+
+// scalar i of this MSM = scalars[gather ? gather[i] : i]; Montgomery unless canonical != 0
+static __global__ void k_msm_digits(const fe *__restrict__ scalars, const uint32_t *__restrict__ gather, uint32_t n,
+                             int canonical, uint32_t c, uint32_t W, uint32_t *__restrict__ keys,
+                             uint32_t *__restrict__ hist) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fe s = scalars[gather ? gather[i] : i];
+    if (!canonical) s = Fr::from_mont(s);
+    const uint32_t nb = 1u << (c - 1), full = 1u << c;
+    uint32_t carry = 0;
+    for (uint32_t w = 0; w < W; w++) {
+        uint32_t bit = w * c, limb = bit >> 5, off = bit & 31;
+        uint32_t d = 0;
+        {
+            uint32_t lo = 0, hi = 0;                            // static selects: keeps the scalar in VGPRs
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) { if (k == limb) lo = s.l[k]; if (k == limb + 1) hi = s.l[k]; }
+            uint64_t v = lo | ((uint64_t)hi << 32);
+            d = (uint32_t)(v >> off) & (full - 1);
+        }
+        d += carry;
+        uint32_t neg = 0;
+        carry = 0;
+        if (d > nb) { d = full - d; neg = 1; carry = 1; }     // digit in [-2^(c-1)+1, 2^(c-1)]
+        uint32_t key = MSM_KEY_NONE;
+        if (d) { key = (d - 1) | (neg << 31); atomicAdd(&hist[w * nb + d - 1], 1u); }
+        keys[(size_t)w * n + i] = key;
+    }
+}
+
+// Single-workgroup exclusive scan over nbk counters: off[b] = entries before bucket b,
+// segoff[b] = segments before bucket b.  Also resets the scatter cursors.  nbk = W * 2^(c-1).
+static __global__ void __launch_bounds__(1024)
+k_msm_scan(const uint32_t *__restrict__ hist, uint32_t nbk, uint32_t *__restrict__ off, uint32_t *__restrict__ segoff,
+           uint32_t *__restrict__ cursor) {
+    __shared__ uint32_t sh_a[1024], sh_b[1024];
+    const uint32_t T = blockDim.x, t = threadIdx.x;
+    const uint32_t per = (nbk + T - 1) / T, b0 = t * per, b1 = (b0 + per < nbk) ? b0 + per : nbk;
+    uint32_t sa = 0, sb = 0;
+    for (uint32_t b = b0; b < b1; b++) { uint32_t h = hist[b]; sa += h; sb += (h + MSM_SEG - 1) / MSM_SEG; }
+    sh_a[t] = sa; sh_b[t] = sb;
+    __syncthreads();
+    for (uint32_t d = 1; d < T; d <<= 1) {                     // Hillis-Steele inclusive scan
+        uint32_t va = 0, vb = 0;
+        if (t >= d) { va = sh_a[t - d]; vb = sh_b[t - d]; }
+        __syncthreads();
+        sh_a[t] += va; sh_b[t] += vb;
+        __syncthreads();
+    }
+    uint32_t ea = sh_a[t] - sa, eb = sh_b[t] - sb;             // exclusive prefix of this thread's run
+    for (uint32_t b = b0; b < b1; b++) {
+        uint32_t h = hist[b];
+        off[b] = ea; segoff[b] = eb; cursor[b] = 0;
+        ea += h; eb += (h + MSM_SEG - 1) / MSM_SEG;
+    }
+    if (t == T - 1) { off[nbk] = sh_a[t]; segoff[nbk] = sh_b[t]; }
+}
+
+static __global__ void k_msm_scatter(const uint32_t *__restrict__ keys, uint32_t n, uint32_t c, uint32_t W,
+                              const uint32_t *__restrict__ off, uint32_t *__restrict__ cursor,
+                              uint32_t *__restrict__ sorted) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t nb = 1u << (c - 1);
+    for (uint32_t w = 0; w < W; w++) {
+        uint32_t key = keys[(size_t)w * n + i];
+        if (key == MSM_KEY_NONE) continue;
+        uint32_t b = w * nb + (key & 0x7fffffffu);
+        uint32_t pos = off[b] + atomicAdd(&cursor[b], 1u);
+        sorted[pos] = i | (key & 0x80000000u);
+    }
+}
+
+// thread per segment; the segment -> bucket map is a binary search in segoff[] (nbk + 1 entries)
+template <class C>
+__global__ void __launch_bounds__(64, C::WAVES_PER_SIMD)
+k_msm_accumulate(const typename C::Affine *__restrict__ bases, const uint32_t *__restrict__ sorted,
+                                 const uint32_t *__restrict__ off, const uint32_t *__restrict__ segoff, uint32_t nbk,
+                                 typename C::XYZZ *__restrict__ segsum) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t nseg = segoff[nbk];
+    if (s >= nseg) return;
+    uint32_t lo = 0, hi = nbk;                                 // largest b with segoff[b] <= s
+    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (segoff[mid] <= s) lo = mid; else hi = mid; }
+    const uint32_t b = lo;
+    uint32_t begin = off[b] + (s - segoff[b]) * MSM_SEG, end = begin + MSM_SEG;
+    if (end > off[b + 1]) end = off[b + 1];
+    typename C::XYZZ acc = C::infinity();
+    for (uint32_t e = begin; e < end; e++) {
+        uint32_t p = sorted[e];
+        typename C::Affine q = bases[p & 0x7fffffffu];
+        if (p >> 31) q = C::neg(q);
+        acc = C::madd(acc, q);
+    }
+    segsum[s] = acc;
+}
+
+// thread per bucket: sum its segment sums (serial; buckets over MSM_HEAVY segments are queued)
+template <class C>
+__global__ void __launch_bounds__(64, C::WAVES_PER_SIMD)
+k_msm_bucket_finalize(const typename C::XYZZ *__restrict__ segsum, const uint32_t *__restrict__ segoff,
+                                      uint32_t nbk, typename C::XYZZ *__restrict__ bucket,
+                                      uint32_t *__restrict__ heavy_list, uint32_t *__restrict__ heavy_count) {
+    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nbk) return;
+    uint32_t s0 = segoff[b], s1 = segoff[b + 1];
+    if (s1 - s0 > MSM_HEAVY) { heavy_list[atomicAdd(heavy_count, 1u)] = b; return; }
+    typename C::XYZZ acc = C::infinity();
+    for (uint32_t s = s0; s < s1; s++) acc = C::add(acc, segsum[s]);
+    bucket[b] = acc;
+}
+
+// workgroups walk the heavy list; 128 threads stride over the bucket's segments, then an LDS tree.
+// LDS holds 64 points (the upper half parks, the lower half adds) to stay inside 64 KiB for G2.
+template <class C>
+__global__ void __launch_bounds__(128)
+k_msm_heavy(const typename C::XYZZ *__restrict__ segsum, const uint32_t *__restrict__ segoff,
+            const uint32_t *__restrict__ heavy_list, const uint32_t *__restrict__ heavy_count,
+            typename C::XYZZ *__restrict__ bucket) {
+    __shared__ typename C::XYZZ sh[64];
+    const uint32_t nheavy = *heavy_count;
+    for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
+        const uint32_t b = heavy_list[h], s0 = segoff[b], s1 = segoff[b + 1];
+        typename C::XYZZ acc = C::infinity();
+        for (uint32_t s = s0 + threadIdx.x; s < s1; s += blockDim.x) acc = C::add(acc, segsum[s]);
+        for (uint32_t half = 64; half > 0; half >>= 1) {
+            if (threadIdx.x >= half && threadIdx.x < 2 * half) sh[threadIdx.x - half] = acc;
+            __syncthreads();
+            if (threadIdx.x < half) acc = C::add(acc, sh[threadIdx.x]);
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) bucket[b] = acc;
+    }
+}
+
+// thread per group of MSM_GROUP buckets of one window:  sum_j (g*K + j + 1) * B_j
+template <class C>
+__global__ void __launch_bounds__(64, C::WAVES_PER_SIMD)
+k_msm_group_reduce(const typename C::XYZZ *__restrict__ bucket, uint32_t c, uint32_t W,
+                                   typename C::XYZZ *__restrict__ partial) {
+    const uint32_t nb = 1u << (c - 1);
+    const uint32_t K = nb < MSM_GROUP ? nb : MSM_GROUP, gpw = nb / K;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= W * gpw) return;
+    const uint32_t w = t / gpw, g = t - w * gpw;
+    const typename C::XYZZ *B = bucket + (size_t)w * nb + (size_t)g * K;
+    typename C::XYZZ run = C::infinity(), acc = C::infinity();
+    for (uint32_t j = K; j-- > 0;) { run = C::add(run, B[j]); acc = C::add(acc, run); }
+    if (g) acc = C::add(acc, C::mul_small(run, g * K));
+    partial[t] = acc;
+}
+
+// out[o] = sum_{i < fan} in[o * fan + i]  (i bounded by per_out_total), contiguous groups
+template <class C>
+__global__ void __launch_bounds__(64, C::WAVES_PER_SIMD)
+k_msm_sum_groups(const typename C::XYZZ *__restrict__ in, uint32_t n_in_per_window, uint32_t fan,
+                                 uint32_t n_out_per_window, uint32_t W, typename C::XYZZ *__restrict__ out) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= W * n_out_per_window) return;
+    const uint32_t w = t / n_out_per_window, o = t - w * n_out_per_window;
+    uint32_t i0 = o * fan, i1 = i0 + fan;
+    if (i1 > n_in_per_window) i1 = n_in_per_window;
+    typename C::XYZZ acc = C::infinity();
+    for (uint32_t i = i0; i < i1; i++) acc = C::add(acc, in[(size_t)w * n_in_per_window + i]);
+    out[t] = acc;
+}
+
+template <class C>
+int MsmWork<C>::alloc(uint32_t n, uint32_t c) {
+        sh.set(n ? n : 1, c);
+        const uint32_t K = sh.nb < MSM_GROUP ? sh.nb : MSM_GROUP;
+        ZK_HIP(hipMalloc(&keys, sizeof(uint32_t) * sh.max_entries()));
+        ZK_HIP(hipMalloc(&sorted, sizeof(uint32_t) * sh.max_entries()));
+        ZK_HIP(hipMalloc(&hist, sizeof(uint32_t) * (sh.nbk + 1)));
+        ZK_HIP(hipMalloc(&off, sizeof(uint32_t) * (sh.nbk + 1)));
+        ZK_HIP(hipMalloc(&segoff, sizeof(uint32_t) * (sh.nbk + 1)));
+        ZK_HIP(hipMalloc(&cursor, sizeof(uint32_t) * (sh.nbk + 1)));
+        ZK_HIP(hipMalloc(&heavy_list, sizeof(uint32_t) * (sh.max_entries() / (MSM_SEG * MSM_HEAVY) + 2)));
+        ZK_HIP(hipMalloc(&heavy_count, sizeof(uint32_t)));
+        ZK_HIP(hipMalloc(&segsum, sizeof(typename C::XYZZ) * sh.max_segments()));
+        ZK_HIP(hipMalloc(&bucket, sizeof(typename C::XYZZ) * sh.nbk));
+        ZK_HIP(hipMalloc(&partial_a, sizeof(typename C::XYZZ) * (size_t)sh.W * (sh.nb / K)));
+        ZK_HIP(hipMalloc(&partial_b, sizeof(typename C::XYZZ) * (size_t)sh.W * (sh.nb / K / MSM_SUMW + 1)));
+        ZK_HIP(hipHostMalloc(&host_windows, sizeof(typename C::XYZZ) * sh.W, hipHostMallocDefault));
+        return ZK_OK;
+    }
+template <class C>
+void MsmWork<C>::release() {
+        void *dev[] = {keys, hist, off, segoff, cursor, sorted, heavy_list, heavy_count, segsum, bucket, partial_a, partial_b};
+        for (void *p : dev) if (p) hipFree(p);
+        if (host_windows) hipHostFree(host_windows);
+        *this = MsmWork();
+    }
+
+template <class C>
+int MsmWork<C>::enqueue(const typename C::Affine *bases, const fe *scalars, const uint32_t *gather, uint32_t n,
+                int canonical, hipStream_t st) {
+        if (n > sh.n) return ZK_ERR_ARG;
+        const uint32_t c = sh.c, W = sh.W, nb = sh.nb, nbk = sh.nbk;
+        const uint32_t K = nb < MSM_GROUP ? nb : MSM_GROUP, gpw = nb / K;
+        ZK_HIP(hipMemsetAsync(hist, 0, sizeof(uint32_t) * (nbk + 1), st));
+        ZK_HIP(hipMemsetAsync(heavy_count, 0, sizeof(uint32_t), st));
+        if (n) ZK_LAUNCH(k_msm_digits, zk_div_up(n, 256), 256, st, scalars, gather, n, canonical, c, W, keys, hist);
+        ZK_LAUNCH_SYNC(k_msm_scan, 1, 1024, st, (const uint32_t *)hist, nbk, off, segoff, cursor);
+        if (n) ZK_LAUNCH(k_msm_scatter, zk_div_up(n, 256), 256, st, (const uint32_t *)keys, n, c, W, (const uint32_t *)off, cursor, sorted);
+        // segment count is only known on the device: launch for the upper bound, threads past segoff[nbk] exit
+        const uint64_t max_seg = (uint64_t)n * W / MSM_SEG + nbk + 1;
+        ZK_LAUNCH(k_msm_accumulate<C>, zk_div_up(max_seg, 64), 64, st, bases, (const uint32_t *)sorted,
+                  (const uint32_t *)off, (const uint32_t *)segoff, nbk, segsum);
+        ZK_LAUNCH(k_msm_bucket_finalize<C>, zk_div_up(nbk, 64), 64, st, (const typename C::XYZZ *)segsum,
+                  (const uint32_t *)segoff, nbk, bucket, heavy_list, heavy_count);
+        ZK_LAUNCH_SYNC(k_msm_heavy<C>, MSM_HEAVY_GRID, 128, st, (const typename C::XYZZ *)segsum, (const uint32_t *)segoff,
+                       (const uint32_t *)heavy_list, (const uint32_t *)heavy_count, bucket);
+        ZK_LAUNCH(k_msm_group_reduce<C>, zk_div_up((uint64_t)W * gpw, 64), 64, st, (const typename C::XYZZ *)bucket, c, W, partial_a);
+        typename C::XYZZ *cur = partial_a, *nxt = partial_b;
+        uint32_t per = gpw;
+        while (per > 1) {
+            uint32_t outp = zk_div_up(per, MSM_SUMW);
+            ZK_LAUNCH(k_msm_sum_groups<C>, zk_div_up((uint64_t)W * outp, 64), 64, st, (const typename C::XYZZ *)cur, per, MSM_SUMW, outp, W, nxt);
+            typename C::XYZZ *t = cur; cur = nxt; nxt = t;
+            per = outp;
+        }
+        ZK_HIP(hipGetLastError());
+        ZK_HIP(hipMemcpyAsync(host_windows, cur, sizeof(typename C::XYZZ) * W, hipMemcpyDeviceToHost, st));
+        return ZK_OK;
+    }
+
+
+}  // namespace zk
