@@ -9,7 +9,7 @@
 //
 // GPU schedule (all integer VALU work, random 64/128-B base gathers from HBM):
 //   1 k_msm_digits      scalar -> canonical -> signed c-bit digits; per-(window,bucket) histogram
-//   2 k_msm_scan        exclusive scans: entries per bucket, and fixed-length *segments* per bucket
+//   2 k_msm_scan_*      exclusive scans: entries per bucket, and fixed-length *segments* per bucket
 //   3 k_msm_scatter     counting-sort scatter of (base index, sign) by bucket
 //   4 k_msm_accumulate  one thread per segment (<= SEG entries): XYZZ mixed additions
 //   5 k_msm_bucket_finalize / k_msm_heavy   segments -> bucket sums (heavy buckets by a workgroup)
@@ -60,9 +60,11 @@ template <class C>
 struct MsmWork {
     MsmShape sh;
     uint32_t *keys = nullptr, *hist = nullptr, *off = nullptr, *segoff = nullptr, *cursor = nullptr, *sorted = nullptr;
-    uint32_t *heavy_list = nullptr, *heavy_count = nullptr;
+    uint32_t *heavy_list = nullptr, *heavy_count = nullptr, *tile_a = nullptr, *tile_b = nullptr;
     typename C::XYZZ *segsum = nullptr, *bucket = nullptr, *partial_a = nullptr, *partial_b = nullptr;
     typename C::XYZZ *host_windows = nullptr;   // pinned, W entries
+    hipEvent_t ev_acc0 = nullptr, ev_acc1 = nullptr;   // bracket k_msm_accumulate (the dominant kernel) on its stream
+    float accumulate_ms() const { float ms = 0; if (ev_acc0 && ev_acc1) hipEventElapsedTime(&ms, ev_acc0, ev_acc1); return ms; }
 
     int alloc(uint32_t n, uint32_t c);
     void release();

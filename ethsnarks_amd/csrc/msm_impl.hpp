@@ -36,32 +36,70 @@ static __global__ void k_msm_digits(const fe *__restrict__ scalars, const uint32
     }
 }
 
-// Single-workgroup exclusive scan over nbk counters: off[b] = entries before bucket b,
-// segoff[b] = segments before bucket b.  Also resets the scatter cursors.  nbk = W * 2^(c-1).
-static __global__ void __launch_bounds__(1024)
-k_msm_scan(const uint32_t *__restrict__ hist, uint32_t nbk, uint32_t *__restrict__ off, uint32_t *__restrict__ segoff,
-           uint32_t *__restrict__ cursor) {
-    __shared__ uint32_t sh_a[1024], sh_b[1024];
-    const uint32_t T = blockDim.x, t = threadIdx.x;
-    const uint32_t per = (nbk + T - 1) / T, b0 = t * per, b1 = (b0 + per < nbk) ? b0 + per : nbk;
-    uint32_t sa = 0, sb = 0;
-    for (uint32_t b = b0; b < b1; b++) { uint32_t h = hist[b]; sa += h; sb += (h + MSM_SEG - 1) / MSM_SEG; }
+// Exclusive scans over the nbk = W * 2^(c-1) bucket counters, three small launches:
+//   off[b]    = entries before bucket b          segoff[b] = fixed-length segments before bucket b
+// k_msm_scan_local: each workgroup scans SCAN_TILE counters (thread-serial runs + LDS Hillis-Steele) and
+// publishes its totals; k_msm_scan_totals: one workgroup scans the tile totals; k_msm_scan_add adds the
+// tile bases, resets the scatter cursors and writes the grand totals off[nbk] / segoff[nbk].
+constexpr uint32_t SCAN_THREADS = 256, SCAN_PER_THREAD = 8, SCAN_TILE = SCAN_THREADS * SCAN_PER_THREAD;
+
+static __global__ void __launch_bounds__(SCAN_THREADS)
+k_msm_scan_local(const uint32_t *__restrict__ hist, uint32_t nbk, uint32_t *__restrict__ off, uint32_t *__restrict__ segoff,
+                 uint32_t *__restrict__ tile_a, uint32_t *__restrict__ tile_b) {
+    __shared__ uint32_t sh_a[SCAN_THREADS], sh_b[SCAN_THREADS];
+    const uint32_t t = threadIdx.x, b0 = blockIdx.x * SCAN_TILE + t * SCAN_PER_THREAD;
+    uint32_t h[SCAN_PER_THREAD], sa = 0, sb = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < SCAN_PER_THREAD; k++) {
+        h[k] = (b0 + k < nbk) ? hist[b0 + k] : 0u;
+        sa += h[k]; sb += (h[k] + MSM_SEG - 1) / MSM_SEG;
+    }
     sh_a[t] = sa; sh_b[t] = sb;
     __syncthreads();
-    for (uint32_t d = 1; d < T; d <<= 1) {                     // Hillis-Steele inclusive scan
+    for (uint32_t d = 1; d < SCAN_THREADS; d <<= 1) {
         uint32_t va = 0, vb = 0;
         if (t >= d) { va = sh_a[t - d]; vb = sh_b[t - d]; }
         __syncthreads();
         sh_a[t] += va; sh_b[t] += vb;
         __syncthreads();
     }
-    uint32_t ea = sh_a[t] - sa, eb = sh_b[t] - sb;             // exclusive prefix of this thread's run
-    for (uint32_t b = b0; b < b1; b++) {
-        uint32_t h = hist[b];
-        off[b] = ea; segoff[b] = eb; cursor[b] = 0;
-        ea += h; eb += (h + MSM_SEG - 1) / MSM_SEG;
+    uint32_t ea = sh_a[t] - sa, eb = sh_b[t] - sb;
+#pragma unroll
+    for (uint32_t k = 0; k < SCAN_PER_THREAD; k++) {
+        if (b0 + k < nbk) { off[b0 + k] = ea; segoff[b0 + k] = eb; }
+        ea += h[k]; eb += (h[k] + MSM_SEG - 1) / MSM_SEG;
     }
-    if (t == T - 1) { off[nbk] = sh_a[t]; segoff[nbk] = sh_b[t]; }
+    if (t == SCAN_THREADS - 1) { tile_a[blockIdx.x] = sh_a[t]; tile_b[blockIdx.x] = sh_b[t]; }
+}
+
+// in-place exclusive scan of the tile totals by one workgroup; totals land in tile_*[ntiles]
+static __global__ void __launch_bounds__(1024)
+k_msm_scan_totals(uint32_t *__restrict__ tile_a, uint32_t *__restrict__ tile_b, uint32_t ntiles) {
+    __shared__ uint32_t sh_a[1024], sh_b[1024];
+    const uint32_t T = blockDim.x, t = threadIdx.x;
+    const uint32_t per = (ntiles + T - 1) / T, i0 = t * per, i1 = (i0 + per < ntiles) ? i0 + per : ntiles;
+    uint32_t sa = 0, sb = 0;
+    for (uint32_t i = i0; i < i1; i++) { sa += tile_a[i]; sb += tile_b[i]; }
+    sh_a[t] = sa; sh_b[t] = sb;
+    __syncthreads();
+    for (uint32_t d = 1; d < T; d <<= 1) {
+        uint32_t va = 0, vb = 0;
+        if (t >= d) { va = sh_a[t - d]; vb = sh_b[t - d]; }
+        __syncthreads();
+        sh_a[t] += va; sh_b[t] += vb;
+        __syncthreads();
+    }
+    uint32_t ea = sh_a[t] - sa, eb = sh_b[t] - sb;
+    for (uint32_t i = i0; i < i1; i++) { uint32_t a = tile_a[i], b = tile_b[i]; tile_a[i] = ea; tile_b[i] = eb; ea += a; eb += b; }
+    if (t == T - 1) { tile_a[ntiles] = sh_a[t]; tile_b[ntiles] = sh_b[t]; }
+}
+
+static __global__ void k_msm_scan_add(uint32_t nbk, uint32_t ntiles, const uint32_t *__restrict__ tile_a,
+                                      const uint32_t *__restrict__ tile_b, uint32_t *__restrict__ off,
+                                      uint32_t *__restrict__ segoff, uint32_t *__restrict__ cursor) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < nbk) { const uint32_t tl = b / SCAN_TILE; off[b] += tile_a[tl]; segoff[b] += tile_b[tl]; cursor[b] = 0; }
+    if (b == nbk) { off[nbk] = tile_a[ntiles]; segoff[nbk] = tile_b[ntiles]; }
 }
 
 static __global__ void k_msm_scatter(const uint32_t *__restrict__ keys, uint32_t n, uint32_t c, uint32_t W,
@@ -185,18 +223,23 @@ int MsmWork<C>::alloc(uint32_t n, uint32_t c) {
         ZK_HIP(hipMalloc(&cursor, sizeof(uint32_t) * (sh.nbk + 1)));
         ZK_HIP(hipMalloc(&heavy_list, sizeof(uint32_t) * (sh.max_entries() / (MSM_SEG * MSM_HEAVY) + 2)));
         ZK_HIP(hipMalloc(&heavy_count, sizeof(uint32_t)));
+        ZK_HIP(hipMalloc(&tile_a, sizeof(uint32_t) * (zk_div_up(sh.nbk, SCAN_TILE) + 1)));
+        ZK_HIP(hipMalloc(&tile_b, sizeof(uint32_t) * (zk_div_up(sh.nbk, SCAN_TILE) + 1)));
         ZK_HIP(hipMalloc(&segsum, sizeof(typename C::XYZZ) * sh.max_segments()));
         ZK_HIP(hipMalloc(&bucket, sizeof(typename C::XYZZ) * sh.nbk));
         ZK_HIP(hipMalloc(&partial_a, sizeof(typename C::XYZZ) * (size_t)sh.W * (sh.nb / K)));
         ZK_HIP(hipMalloc(&partial_b, sizeof(typename C::XYZZ) * (size_t)sh.W * (sh.nb / K / MSM_SUMW + 1)));
         ZK_HIP(hipHostMalloc(&host_windows, sizeof(typename C::XYZZ) * sh.W, hipHostMallocDefault));
+        ZK_HIP(hipEventCreate(&ev_acc0)); ZK_HIP(hipEventCreate(&ev_acc1));
         return ZK_OK;
     }
 template <class C>
 void MsmWork<C>::release() {
-        void *dev[] = {keys, hist, off, segoff, cursor, sorted, heavy_list, heavy_count, segsum, bucket, partial_a, partial_b};
+        void *dev[] = {keys, hist, off, segoff, cursor, sorted, heavy_list, heavy_count, tile_a, tile_b, segsum, bucket, partial_a, partial_b};
         for (void *p : dev) if (p) hipFree(p);
         if (host_windows) hipHostFree(host_windows);
+        if (ev_acc0) hipEventDestroy(ev_acc0);
+        if (ev_acc1) hipEventDestroy(ev_acc1);
         *this = MsmWork();
     }
 
@@ -209,12 +252,19 @@ int MsmWork<C>::enqueue(const typename C::Affine *bases, const fe *scalars, cons
         ZK_HIP(hipMemsetAsync(hist, 0, sizeof(uint32_t) * (nbk + 1), st));
         ZK_HIP(hipMemsetAsync(heavy_count, 0, sizeof(uint32_t), st));
         if (n) ZK_LAUNCH(k_msm_digits, zk_div_up(n, 256), 256, st, scalars, gather, n, canonical, c, W, keys, hist);
-        ZK_LAUNCH_SYNC(k_msm_scan, 1, 1024, st, (const uint32_t *)hist, nbk, off, segoff, cursor);
+        {
+            const uint32_t ntiles = zk_div_up(nbk, SCAN_TILE);
+            ZK_LAUNCH_SYNC(k_msm_scan_local, ntiles, SCAN_THREADS, st, (const uint32_t *)hist, nbk, off, segoff, tile_a, tile_b);
+            ZK_LAUNCH_SYNC(k_msm_scan_totals, 1, 1024, st, tile_a, tile_b, ntiles);
+            ZK_LAUNCH(k_msm_scan_add, zk_div_up(nbk + 1, 256), 256, st, nbk, ntiles, (const uint32_t *)tile_a, (const uint32_t *)tile_b, off, segoff, cursor);
+        }
         if (n) ZK_LAUNCH(k_msm_scatter, zk_div_up(n, 256), 256, st, (const uint32_t *)keys, n, c, W, (const uint32_t *)off, cursor, sorted);
         // segment count is only known on the device: launch for the upper bound, threads past segoff[nbk] exit
         const uint64_t max_seg = (uint64_t)n * W / MSM_SEG + nbk + 1;
+        ZK_HIP(hipEventRecord(ev_acc0, st));
         ZK_LAUNCH(k_msm_accumulate<C>, zk_div_up(max_seg, 64), 64, st, bases, (const uint32_t *)sorted,
                   (const uint32_t *)off, (const uint32_t *)segoff, nbk, segsum);
+        ZK_HIP(hipEventRecord(ev_acc1, st));
         ZK_LAUNCH(k_msm_bucket_finalize<C>, zk_div_up(nbk, 64), 64, st, (const typename C::XYZZ *)segsum,
                   (const uint32_t *)segoff, nbk, bucket, heavy_list, heavy_count);
         ZK_LAUNCH_SYNC(k_msm_heavy<C>, MSM_HEAVY_GRID, 128, st, (const typename C::XYZZ *)segsum, (const uint32_t *)segoff,

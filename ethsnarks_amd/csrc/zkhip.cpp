@@ -14,6 +14,7 @@
 #include "bn254.hpp"
 #include "ntt.hpp"
 #include "msm.hpp"
+#include "keygen.hpp"
 #include "../../include/zkhip.h"
 
 namespace zk { thread_local char g_last_error[256] = ""; }
@@ -290,6 +291,7 @@ Range shard_range(uint32_t n, uint32_t rank, uint32_t count) {
 
 struct zk_ctx {
     int device = 0;
+    bool serial = false;
     uint32_t nC = 0, nIn = 0, V = 0, m = 0, logm = 0;
     zk_config cfg{};
     G1::Affine alpha_g1; G2::Affine beta_g2;
@@ -315,6 +317,7 @@ struct zk_ctx {
         cA.release(); cB.release(); cC.release();
         ntt_tables_free(tab);
         mA.release(); mH.release(); mL.release(); mB.release();
+        if (serial) s_a = s_b = s_l = nullptr;
         hipStream_t ss[] = {s_main, s_a, s_b, s_l};
         for (auto s : ss) if (s) hipStreamDestroy(s);
         hipEvent_t ee[] = {ev_start, ev_w, ev_h, ev_a0, ev_a1, ev_b0, ev_b1, ev_l0, ev_l1, ev_h1};
@@ -348,10 +351,19 @@ static int ctx_build(zk_ctx *c, const zk_pk *pk, const zk_csr *A, const zk_csr *
     ZK_HIP(hipMalloc(&c->d_c, 32 * (size_t)m)); ZK_HIP(hipMalloc(&c->d_t, 32 * (size_t)m));
     ZK_HIP(hipHostMalloc(&c->h_w, 32 * (size_t)(V + 1), hipHostMallocDefault));
     ZK_HIP(hipHostMalloc(&c->h_tail, 32, hipHostMallocDefault));
-    ZK_HIP(hipStreamCreateWithFlags(&c->s_main, hipStreamNonBlocking));
-    ZK_HIP(hipStreamCreateWithFlags(&c->s_a, hipStreamNonBlocking));
-    ZK_HIP(hipStreamCreateWithFlags(&c->s_b, hipStreamNonBlocking));
-    ZK_HIP(hipStreamCreateWithFlags(&c->s_l, hipStreamNonBlocking));
+    // s_main carries the critical chain (H polynomial -> H-query): highest priority; the A-, B-, L-query
+    // streams fill the machine beside it.  ZK_SERIAL=1 (profiling aid) puts everything on s_main.
+    int prio_lo = 0, prio_hi = 0;
+    ZK_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+    ZK_HIP(hipStreamCreateWithPriority(&c->s_main, hipStreamNonBlocking, prio_hi));
+    const char *serial = getenv("ZK_SERIAL");
+    c->serial = serial && serial[0] == '1';
+    if (c->serial) { c->s_a = c->s_b = c->s_l = c->s_main; }
+    else {
+        ZK_HIP(hipStreamCreateWithPriority(&c->s_a, hipStreamNonBlocking, prio_lo));
+        ZK_HIP(hipStreamCreateWithPriority(&c->s_b, hipStreamNonBlocking, prio_lo));
+        ZK_HIP(hipStreamCreateWithPriority(&c->s_l, hipStreamNonBlocking, prio_lo));
+    }
     hipEvent_t *ee[] = {&c->ev_start, &c->ev_w, &c->ev_h, &c->ev_a0, &c->ev_a1, &c->ev_b0, &c->ev_b1, &c->ev_l0, &c->ev_l1, &c->ev_h1};
     for (auto e : ee) ZK_HIP(hipEventCreate(e));
     ZK_TRY(ntt_tables_create(c->tab, c->logm, c->s_main));
@@ -464,6 +476,8 @@ static int prove_partial_impl(zk_ctx *c, const uint64_t *witness, int canonical,
         tm->gpu_total = ta; if (tb > tm->gpu_total) tm->gpu_total = tb;
         if (tl > tm->gpu_total) tm->gpu_total = tl; if (th > tm->gpu_total) tm->gpu_total = th;
         tm->host_finish = (float)(now_ms() - t0);
+        tm->acc_a = c->mA.accumulate_ms(); tm->acc_b = c->mB.accumulate_ms();
+        tm->acc_h = c->mH.accumulate_ms(); tm->acc_l = c->mL.accumulate_ms();
     }
     return ZK_OK;
 }
@@ -503,6 +517,9 @@ extern "C" int zk_prove_combine(const zk_ctx *c, const zk_partials *parts, uint3
 extern "C" int zk_prove_partial(zk_ctx *ctx, const uint64_t *witness, int canonical, zk_partials *out) {
     return prove_partial_impl(ctx, witness, canonical, out, nullptr);
 }
+extern "C" int zk_prove_partial_timed(zk_ctx *ctx, const uint64_t *witness, int canonical, zk_partials *out, zk_timings *t) {
+    return prove_partial_impl(ctx, witness, canonical, out, t);
+}
 extern "C" int zk_prove_timed(zk_ctx *ctx, const uint64_t *witness, int canonical, zk_proof *out, zk_timings *t) {
     if (!ctx || !out) return fail(ZK_ERR_ARG, "null argument");
     if (ctx->cfg.shard_count > 1) return fail(ZK_ERR_ARG, "sharded context: use zk_prove_partial + zk_prove_combine");
@@ -515,6 +532,133 @@ extern "C" int zk_prove_timed(zk_ctx *ctx, const uint64_t *witness, int canonica
 }
 extern "C" int zk_prove(zk_ctx *ctx, const uint64_t *witness, int canonical, zk_proof *out) {
     return zk_prove_timed(ctx, witness, canonical, out, nullptr);
+}
+
+
+// ================================================================ key generation
+// r1cs_gg_ppzksnark_zok_generator (tcc:277-449) with r1cs_to_qap_instance_map_with_evaluation
+//  and the zk -> nozk conversion of hpp:209-233.
+struct zk_vk {
+    G1::Affine alpha_g1; G2::Affine beta_g2, gamma_g2, delta_g2;
+    std::vector<G1::Affine> gamma_abc;
+};
+extern "C" void zk_vk_free(zk_vk *vk) { delete vk; }
+
+namespace {
+// standard alt_bn128 G2 generator, canonical 32-bit limbs: x.c0, x.c1, y.c0, y.c1
+const uint32_t G2_GEN_CANON[4][8] = {
+    {0xd992f6edu, 0x46debd5cu, 0xf75edaddu, 0x674322d4u, 0x5e5c4479u, 0x426a0066u, 0x121f1e76u, 0x1800deefu},
+    {0xaef312c2u, 0x97e485b7u, 0x35a9e712u, 0xf1aa4933u, 0x31fb5d25u, 0x7260bfb7u, 0x920d483au, 0x198e9393u},
+    {0x66fa7daau, 0x4ce6cc01u, 0x0c43d37bu, 0xe3d1e769u, 0x8dcb408fu, 0x4aab7180u, 0xdb8c6debu, 0x12c85ea5u},
+    {0xd122975bu, 0x55acdadcu, 0x70b38ef3u, 0xbc4b3133u, 0x690c3395u, 0xec9e99adu, 0x585ff075u, 0x090689d0u}};
+fe fq_from_canon32(const uint32_t v[8]) { fe t; for (int i = 0; i < 8; i++) t.l[i] = v[i]; return Fq::to_mont(t); }
+
+void fr_batch_inverse(std::vector<fe> &a) {          // Montgomery's trick; zeros stay zero
+    std::vector<fe> pre(a.size());
+    fe acc = Fr::one();
+    for (size_t i = 0; i < a.size(); i++) { pre[i] = acc; if (!Fr::is_zero(a[i])) acc = Fr::mul(acc, a[i]); }
+    acc = Fr::inv(acc);
+    for (size_t i = a.size(); i-- > 0;) {
+        if (Fr::is_zero(a[i])) continue;
+        fe t = Fr::mul(acc, pre[i]); acc = Fr::mul(acc, a[i]); a[i] = t;
+    }
+}
+template <class C>
+int batch_mul_host(const typename C::Affine &base, const std::vector<fe> &scalars, std::vector<typename C::Affine> &out) {
+    out.resize(scalars.size());
+    if (scalars.empty()) return ZK_OK;
+    fe *d_s = nullptr; typename C::Affine *d_o = nullptr;
+    int rc = dev_upload(&d_s, scalars.data(), scalars.size());
+    if (rc == ZK_OK && hipMalloc(&d_o, sizeof(typename C::Affine) * scalars.size()) != hipSuccess) rc = ZK_ERR_NOMEM;
+    if (rc == ZK_OK) rc = batch_mul_base<C>(base, d_s, (uint32_t)scalars.size(), d_o, nullptr);
+    if (rc == ZK_OK && hipDeviceSynchronize() != hipSuccess) rc = fail(ZK_ERR_HIP, "batch_mul_base kernel failed");
+    if (rc == ZK_OK && hipMemcpy(out.data(), d_o, sizeof(typename C::Affine) * scalars.size(), hipMemcpyDeviceToHost) != hipSuccess) rc = ZK_ERR_HIP;
+    if (d_s) hipFree(d_s);
+    if (d_o) hipFree(d_o);
+    return rc;
+}
+}  // namespace
+
+extern "C" int zk_keygen(const zk_csr *A, const zk_csr *B, const zk_csr *C, uint32_t nC, uint32_t nIn, uint32_t V,
+                         const uint64_t toxic_canon[20], int device, zk_pk **pk_out, zk_vk **vk_out) {
+    if (!A || !B || !C || !toxic_canon || !pk_out || !vk_out) return fail(ZK_ERR_ARG, "null argument");
+    if (A->n_rows != nC || B->n_rows != nC || C->n_rows != nC || nIn > V) return fail(ZK_ERR_ARG, "inconsistent constraint system");
+    if ((uint64_t)nC + nIn + 1 > (1ull << 28)) return fail(ZK_ERR_ARG, "domain exceeds 2^28");
+    ZK_TRY(use_device(device));
+    const uint32_t m = zk_domain_size(nC, nIn);
+    uint32_t logm = 0; while ((1u << logm) < m) logm++;
+    fe tox[5];
+    for (int i = 0; i < 5; i++) { fe c; memcpy(c.l, toxic_canon + 4 * i, 32); tox[i] = Fr::to_mont(c); }
+    const fe t = tox[0], alpha = tox[1], beta = tox[2], gamma = tox[3], delta = tox[4];
+    if (Fr::is_zero(gamma) || Fr::is_zero(delta)) return fail(ZK_ERR_ARG, "gamma and delta must be invertible");
+    // Lagrange basis at t: u_i = omega^i (t^m - 1) / (m (t - omega^i)); indicator vector if t is in the domain
+    const fe w = fr_domain_root(logm), Zt = Fr::sub(Fr::pow_u64(t, m), Fr::one()), mfe = Fr::from_u64(m);
+    std::vector<fe> u(m), den(m);
+    fe wi = Fr::one();
+    for (uint32_t i = 0; i < m; i++) {
+        fe d = Fr::sub(t, wi);
+        den[i] = Fr::mul(d, mfe);
+        u[i] = Fr::is_zero(d) ? Fr::one() : Fr::mul(wi, Zt);
+        if (Fr::is_zero(d)) den[i] = Fr::one();
+        wi = Fr::mul(wi, w);
+    }
+    fr_batch_inverse(den);
+    for (uint32_t i = 0; i < m; i++) u[i] = Fr::mul(u[i], den[i]);
+    std::vector<fe> At(V + 1, Fr::zero()), Bt(V + 1, Fr::zero()), Ct(V + 1, Fr::zero());
+    for (uint32_t i = 0; i <= nIn; i++) At[i] = u[nC + i];
+    const zk_csr *Ms[3] = {A, B, C}; std::vector<fe> *Ts[3] = {&At, &Bt, &Ct};
+    for (int q = 0; q < 3; q++) {
+        const zk_csr *M = Ms[q];
+        if (M->row_ptr[0] != 0) return fail(ZK_ERR_ARG, "CSR row_ptr[0] != 0");
+        for (uint32_t j = 0; j < nC; j++)
+            for (uint32_t k = M->row_ptr[j]; k < M->row_ptr[j + 1]; k++) {
+                if (M->col[k] > V) return fail(ZK_ERR_ARG, "CSR column index exceeds the number of variables");
+                fe cf; memcpy(cf.l, M->coeff + 4 * (size_t)k, 32);
+                fe p = fr_is_one(cf) ? u[j] : Fr::mul(u[j], cf);
+                fe &dst = (*Ts[q])[M->col[k]];
+                dst = Fr::add(dst, p);
+            }
+    }
+    const fe gi = Fr::inv(gamma), di = Fr::inv(delta);
+    // G1 scalars: [alpha, beta, delta | gammaABC (nIn+1) | A (non-zero) | H (m-1) | L (V-nIn)]
+    std::vector<fe> s1, s2;
+    zk_pk *pk = new (std::nothrow) zk_pk(); zk_vk *vk = new (std::nothrow) zk_vk();
+    if (!pk || !vk) { delete pk; delete vk; return ZK_ERR_NOMEM; }
+    pk->a_domain = V + 1; pk->b_domain = V + 1;
+    s1.push_back(alpha); s1.push_back(beta); s1.push_back(delta);
+    s2.push_back(beta); s2.push_back(gamma); s2.push_back(delta);
+    std::vector<fe> abc(V + 1);
+    for (uint32_t i = 0; i <= V; i++) {                      // (beta At + alpha Bt + Ct) / {gamma | delta}, tcc:326-342
+        fe v = Fr::add(Fr::add(Fr::mul(beta, At[i]), Fr::mul(alpha, Bt[i])), Ct[i]);
+        abc[i] = Fr::mul(v, i <= nIn ? gi : di);
+    }
+    for (uint32_t i = 0; i <= nIn; i++) s1.push_back(abc[i]);
+    for (uint32_t i = 0; i <= V; i++) if (!Fr::is_zero(At[i])) { pk->a_idx.push_back(i); s1.push_back(At[i]); }   // hpp:216-224
+    for (uint32_t i = 0; i <= V; i++) if (!Fr::is_zero(Bt[i])) { pk->b_idx.push_back(i); s2.push_back(Bt[i]); }   // hpp:225-230
+    {
+        fe zd = Fr::mul(Zt, di), tj = Fr::one();               // H_j = t^j Zt / delta, j < m-1 (tcc:350,400)
+        for (uint32_t j = 0; j + 1 < m; j++) { s1.push_back(Fr::mul(tj, zd)); tj = Fr::mul(tj, t); }
+    }
+    for (uint32_t i = nIn + 1; i <= V; i++) s1.push_back(abc[i]);
+    G1::Affine g1; g1.x = Fq::from_u64(1); g1.y = Fq::from_u64(2);
+    G2::Affine g2;
+    g2.x.c0 = fq_from_canon32(G2_GEN_CANON[0]); g2.x.c1 = fq_from_canon32(G2_GEN_CANON[1]);
+    g2.y.c0 = fq_from_canon32(G2_GEN_CANON[2]); g2.y.c1 = fq_from_canon32(G2_GEN_CANON[3]);
+    std::vector<G1::Affine> o1; std::vector<G2::Affine> o2;
+    int rc = batch_mul_host<G1>(g1, s1, o1);
+    if (rc == ZK_OK) rc = batch_mul_host<G2>(g2, s2, o2);
+    if (rc != ZK_OK) { delete pk; delete vk; return rc; }
+    size_t k = 0;
+    pk->alpha_g1 = o1[k++]; pk->beta_g1 = o1[k++]; pk->delta_g1 = o1[k++];
+    vk->gamma_abc.assign(o1.begin() + k, o1.begin() + k + nIn + 1); k += nIn + 1;
+    pk->a_val.assign(o1.begin() + k, o1.begin() + k + pk->a_idx.size()); k += pk->a_idx.size();
+    pk->H.assign(o1.begin() + k, o1.begin() + k + (m - 1)); k += m - 1;
+    pk->L.assign(o1.begin() + k, o1.end());
+    pk->beta_g2 = o2[0]; pk->delta_g2 = o2[2];
+    pk->b_val.assign(o2.begin() + 3, o2.end());
+    vk->alpha_g1 = pk->alpha_g1; vk->beta_g2 = o2[0]; vk->gamma_g2 = o2[1]; vk->delta_g2 = o2[2];
+    *pk_out = pk; *vk_out = vk;
+    return ZK_OK;
 }
 
 // ================================================================ JSON (src/export.cpp:20-121)
@@ -549,6 +693,34 @@ extern "C" int zk_proof_to_json(const zk_proof *p, const uint64_t *inputs, uint3
         if (i + 1 < nIn) s += ", ";
     }
     s += "]\n}";
+    *len = s.size();
+    if (!buf || cap < s.size() + 1) return fail(ZK_ERR_BUFFER, "JSON buffer too small");
+    memcpy(buf, s.data(), s.size()); buf[s.size()] = 0;
+    return ZK_OK;
+}
+
+
+// vk2json, src/export.cpp:124-145
+extern "C" int zk_vk_to_json(const zk_vk *vk, char *buf, size_t cap, size_t *len) {
+    if (!vk || !len) return fail(ZK_ERR_ARG, "null argument");
+    std::string s;
+    auto g1 = [&](const G1::Affine &p) {
+        uint64_t x[4], y[4]; uint32_t inf;
+        put_g1(G1::from_affine(p), x, y, &inf);
+        q(s, x); s += ", "; q(s, y);
+    };
+    auto g2 = [&](const G2::Affine &p) {
+        uint64_t a[4], b[4], c[4], d[4]; uint32_t inf;
+        put_g2(G2::from_affine(p), a, b, c, d, &inf);
+        s += "["; q(s, b); s += ", "; q(s, a); s += "],\n ["; q(s, d); s += ", "; q(s, c); s += "]";
+    };
+    s += "{\n \"alpha\" :["; g1(vk->alpha_g1);
+    s += "],\n \"beta\"  :["; g2(vk->beta_g2);
+    s += "],\n \"gamma\" :["; g2(vk->gamma_g2);
+    s += "],\n \"delta\" :["; g2(vk->delta_g2);
+    s += "],\n\"gammaABC\" :[[";
+    for (size_t i = 0; i < vk->gamma_abc.size(); i++) { if (i) s += ",["; g1(vk->gamma_abc[i]); s += "]"; }
+    s += "]}";
     *len = s.size();
     if (!buf || cap < s.size() + 1) return fail(ZK_ERR_BUFFER, "JSON buffer too small");
     memcpy(buf, s.data(), s.size()); buf[s.size()] = 0;

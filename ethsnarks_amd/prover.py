@@ -47,7 +47,8 @@ class ZkPartials(C.Structure):
 
 
 class ZkTimings(C.Structure):
-    _fields_ = [(n, C.c_float) for n in ("h2d_witness", "compute_h", "a_query", "b_query", "h_query", "l_query", "gpu_total", "host_finish")]
+    _fields_ = [(n, C.c_float) for n in ("h2d_witness", "compute_h", "a_query", "b_query", "h_query", "l_query", "gpu_total", "host_finish",
+                                             "acc_a", "acc_b", "acc_h", "acc_l")]
 
     def as_dict(self):
         return {n: float(getattr(self, n)) for n, _ in self._fields_}
@@ -56,8 +57,9 @@ class ZkTimings(C.Structure):
 EXPORTS = [
     "zk_version", "zk_strerror", "zk_last_error", "zk_device_count",
     "zk_pk_load_raw", "zk_pk_save_raw", "zk_pk_from_parts", "zk_pk_sizes", "zk_pk_part", "zk_pk_free",
+    "zk_keygen", "zk_vk_to_json", "zk_vk_free",
     "zk_domain_size", "zk_ctx_create", "zk_ctx_destroy",
-    "zk_prove", "zk_prove_timed", "zk_prove_partial", "zk_prove_combine", "zk_proof_to_json",
+    "zk_prove", "zk_prove_timed", "zk_prove_partial", "zk_prove_partial_timed", "zk_prove_combine", "zk_proof_to_json",
     "zk_ntt", "zk_witness_map", "zk_msm_g1", "zk_msm_g2", "zk_field_mul",
 ]
 
@@ -169,6 +171,72 @@ def load_proving_key(pk_file, codec=0):
     return ProvingKey(h)
 
 
+class VerificationKey:
+    """r1cs_gg_ppzksnark_zok_verification_key (hpp:296-350); only what keygen hands out."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    def to_json(self):
+        """vk2json (src/export.cpp:124-145)."""
+        ln = C.c_size_t(0)
+        _lib.zk_vk_to_json(self._h, None, C.c_size_t(0), C.byref(ln))
+        buf = C.create_string_buffer(ln.value + 1)
+        _check(_lib.zk_vk_to_json(self._h, buf, C.c_size_t(ln.value + 1), C.byref(ln)))
+        return buf.raw[:ln.value].decode()
+
+    def close(self):
+        if self._h is not None and _lib is not None:
+            _lib.zk_vk_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _csr_structs(r1cs, keep):
+    def csr(m):
+        rp = np.ascontiguousarray(m.row_ptr, dtype=np.uint32)
+        co = np.ascontiguousarray(m.col, dtype=np.uint32)
+        cf = _c64(m.coeff)
+        keep.extend([rp, co, cf])
+        return ZkCSR(m.n_rows, _p32(rp), _p32(co), _p64(cf))
+    return csr(r1cs.A), csr(r1cs.B), csr(r1cs.C)
+
+
+def keygen(r1cs, toxic=None, seed=None, device=0):
+    """r1cs_gg_ppzksnark_zok_generator + nozk conversion (tcc:277-449, hpp:209-233) on the GPU.
+    toxic = (t, alpha, beta, gamma, delta) ints; or seed -> 5 SplitMix64 draws; default os.urandom."""
+    lib = load_library(_lib_path_loaded)
+    from .fields import FR, ints_to_limbs
+    if toxic is None:
+        if seed is not None:
+            from .r1cs import SplitMix64
+            rng = SplitMix64(seed)
+            toxic = [rng.fr() for _ in range(5)]
+        else:
+            toxic = [int.from_bytes(os.urandom(40), "little") % FR for _ in range(5)]
+    tox = np.ascontiguousarray(ints_to_limbs([t % FR for t in toxic])).reshape(-1)
+    keep = []
+    a, b, c = _csr_structs(r1cs, keep)
+    pk, vk = C.c_void_p(), C.c_void_p()
+    _check(lib.zk_keygen(C.byref(a), C.byref(b), C.byref(c), C.c_uint32(r1cs.nC), C.c_uint32(r1cs.nIn), C.c_uint32(r1cs.V),
+                         _p64(tox), device, C.byref(pk), C.byref(vk)))
+    return ProvingKey(pk), VerificationKey(vk)
+
+
+def stub_genkeys_from_pb(r1cs, pk_file, vk_file, **kw):
+    """ethsnarks::stub_genkeys_from_pb (src/stubs.cpp:77-87): vk JSON + nozk .raw proving key."""
+    pk, vk = keygen(r1cs, **kw)
+    with open(vk_file, "wb") as f:                     # vk2json_file, src/export.cpp:148-155
+        f.write(vk.to_json().encode())
+    pk.save_raw(pk_file)
+    return 0
+
+
 def get_domain_size(r1cs):
     """size of the domain ethsnarks::get_domain builds (src/stubs.cpp:61-75)."""
     return int(load_library(_lib_path_loaded).zk_domain_size(C.c_uint32(r1cs.nC), C.c_uint32(r1cs.nIn)))
@@ -181,14 +249,7 @@ class ProverContext:
         lib = load_library(_lib_path_loaded)
         self.r1cs = r1cs
         self._keep = []
-
-        def csr(m):
-            rp = np.ascontiguousarray(m.row_ptr, dtype=np.uint32)
-            co = np.ascontiguousarray(m.col, dtype=np.uint32)
-            cf = _c64(m.coeff)
-            self._keep += [rp, co, cf]
-            return ZkCSR(m.n_rows, _p32(rp), _p32(co), _p64(cf))
-        a, b, c = csr(r1cs.A), csr(r1cs.B), csr(r1cs.C)
+        a, b, c = _csr_structs(r1cs, self._keep)
         cfg = ZkConfig(multi_exp_c, device, shard_rank, shard_count)
         h = C.c_void_p()
         _check(lib.zk_ctx_create(pk._h, C.byref(a), C.byref(b), C.byref(c), C.c_uint32(r1cs.nC), C.c_uint32(r1cs.nIn),
@@ -213,9 +274,13 @@ class ProverContext:
         _check(_lib.zk_prove(self._h, _p64(w), int(canonical), C.byref(proof)))
         return proof
 
-    def prove_partial(self, witness, canonical=False):
+    def prove_partial(self, witness, canonical=False, timings=False):
         w = self._w(witness)
         part = ZkPartials()
+        if timings:
+            t = ZkTimings()
+            _check(_lib.zk_prove_partial_timed(self._h, _p64(w), int(canonical), C.byref(part), C.byref(t)))
+            return np.frombuffer(bytes(part), dtype=np.uint64).copy(), t.as_dict()
         _check(_lib.zk_prove_partial(self._h, _p64(w), int(canonical), C.byref(part)))
         return np.frombuffer(bytes(part), dtype=np.uint64).copy()      # 80 u64 = 640 bytes
 

@@ -12,6 +12,9 @@
  *   zk_prove            <- r1cs_gg_ppzksnark_zok_prover(ctx, pb.values)      tcc:451-550 (via prove(), stubs.cpp:42-47)
  *   zk_proof_to_json    <- proof_to_json(proof, primary_input)               src/export.cpp:99-121
  *   zk_config           <- libsnark::Config                                   src/prover_config.hpp:8-35
+ *   zk_keygen           <- r1cs_gg_ppzksnark_zok_generator + nozk conversion  tcc:277-449, hpp:209-233
+ *                          (stub_genkeys_from_pb, src/stubs.cpp:77-87)
+ *   zk_vk_to_json       <- vk2json                                            src/export.cpp:124-145
  *
  * Plain C types only.  Field elements are 4 x u64 little-endian limbs; "Montgomery" means the
  * libff::Fp_model<4> in-memory form (value * 2^256 mod p), which is what `pb.values` and the `.raw`
@@ -44,6 +47,7 @@ extern "C" {
 #define ZK_CODEC_ALT_BN128 0   /* upstream libff layout; the only codec validated so far */
 
 typedef struct zk_pk zk_pk;
+typedef struct zk_vk zk_vk;
 typedef struct zk_ctx zk_ctx;
 
 typedef struct {
@@ -84,6 +88,7 @@ typedef struct {
     float a_query, b_query, h_query, l_query;   /* GPU time of each multi-exponentiation */
     float gpu_total;           /* first kernel to last copy */
     float host_finish;         /* window Horner, final additions, affine conversion */
+    float acc_a, acc_b, acc_h, acc_l;   /* k_msm_accumulate launch of each query, HIP events on its stream */
 } zk_timings;
 
 /* ---- library / device */
@@ -106,6 +111,15 @@ int zk_pk_sizes(const zk_pk *pk, uint32_t sizes[6]);
 const void *zk_pk_part(const zk_pk *pk, int which);
 void zk_pk_free(zk_pk *pk);
 
+/* ---- key generation: the QAP is evaluated at t on the host, the fixed-base
+ * exponentiations (A, B, H, L queries, gammaABC) run on the GPU.
+ * toxic_canon = t, alpha, beta, gamma, delta as canonical 4 x u64 each (the reference draws them with
+ * Fr::random_element(), tcc:283-287).  Generators: G1 (1, 2), G2 the standard alt_bn128 generator. */
+int zk_keygen(const zk_csr *A, const zk_csr *B, const zk_csr *C, uint32_t nC, uint32_t nIn, uint32_t V,
+              const uint64_t toxic_canon[20], int device, zk_pk **pk_out, zk_vk **vk_out);
+int zk_vk_to_json(const zk_vk *vk, char *buf, size_t cap, size_t *len);
+void zk_vk_free(zk_vk *vk);
+
 /* ---- prover context: uploads bases + CSR once, builds domain tables, owns all scratch.
  * Borrows nothing after return (pk and CSR may be freed), one context per concurrent prover. */
 uint32_t zk_domain_size(uint32_t nC, uint32_t nIn);                      /* src/stubs.cpp:49-65 */
@@ -119,6 +133,7 @@ int zk_prove_timed(zk_ctx *ctx, const uint64_t *witness, int canonical, zk_proof
 /* sharded contexts: each rank computes its partial sums; after exchanging them (e.g. an RCCL
  * all-gather of the 640-byte structs), any rank folds them in rank order and finishes the proof */
 int zk_prove_partial(zk_ctx *ctx, const uint64_t *witness, int canonical, zk_partials *out);
+int zk_prove_partial_timed(zk_ctx *ctx, const uint64_t *witness, int canonical, zk_partials *out, zk_timings *t);
 int zk_prove_combine(const zk_ctx *ctx, const zk_partials *parts, uint32_t count, zk_proof *out);
 
 /* inputs: nIn Fr elements = witness[1..nIn] (Montgomery unless canonical); returns the JSON length

@@ -46,6 +46,13 @@ static const fq2_t fq2_ONE = {{{0xd35d438dc58f0d9dULL, 0x0a78eb28f5c70b3dULL, 0x
 #undef AFF
 
 static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+void orc_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
 int orc_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -101,6 +101,7 @@ int orc_prove(const orc_pk *, const orc_r1cs *cs, const uint64_t *witness, unsig
 /* inputs: nIn Montgomery Fr elements (witness[1..nIn]); returns bytes needed (excluding NUL) */
 size_t orc_proof_to_json(const orc_proof *, const uint64_t *inputs, uint32_t nIn, char *buf, size_t cap);
 int orc_num_threads(void);
+void orc_set_threads(int n);   /* OpenMP team size; callers set it to the container's CPU share */
 
 #ifdef __cplusplus
 }
