@@ -7,7 +7,9 @@
 namespace zk {
 
 // scalar i of this MSM = scalars[gather ? gather[i] : i]; Montgomery unless canonical != 0
-static __global__ void k_msm_digits(const fe *__restrict__ scalars, const uint32_t *__restrict__ gather, uint32_t n,
+template <class C>
+__global__ void
+k_msm_digits(const fe *__restrict__ scalars, const uint32_t *__restrict__ gather, uint32_t n,
                              int canonical, uint32_t c, uint32_t W, uint32_t *__restrict__ keys,
                              uint32_t *__restrict__ hist) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -43,7 +45,8 @@ static __global__ void k_msm_digits(const fe *__restrict__ scalars, const uint32
 // tile bases, resets the scatter cursors and writes the grand totals off[nbk] / segoff[nbk].
 constexpr uint32_t SCAN_THREADS = 256, SCAN_PER_THREAD = 8, SCAN_TILE = SCAN_THREADS * SCAN_PER_THREAD;
 
-static __global__ void __launch_bounds__(SCAN_THREADS)
+template <class C>
+__global__ void __launch_bounds__(SCAN_THREADS)
 k_msm_scan_local(const uint32_t *__restrict__ hist, uint32_t nbk, uint32_t *__restrict__ off, uint32_t *__restrict__ segoff,
                  uint32_t *__restrict__ tile_a, uint32_t *__restrict__ tile_b) {
     __shared__ uint32_t sh_a[SCAN_THREADS], sh_b[SCAN_THREADS];
@@ -73,7 +76,8 @@ k_msm_scan_local(const uint32_t *__restrict__ hist, uint32_t nbk, uint32_t *__re
 }
 
 // in-place exclusive scan of the tile totals by one workgroup; totals land in tile_*[ntiles]
-static __global__ void __launch_bounds__(1024)
+template <class C>
+__global__ void __launch_bounds__(1024)
 k_msm_scan_totals(uint32_t *__restrict__ tile_a, uint32_t *__restrict__ tile_b, uint32_t ntiles) {
     __shared__ uint32_t sh_a[1024], sh_b[1024];
     const uint32_t T = blockDim.x, t = threadIdx.x;
@@ -94,7 +98,9 @@ k_msm_scan_totals(uint32_t *__restrict__ tile_a, uint32_t *__restrict__ tile_b, 
     if (t == T - 1) { tile_a[ntiles] = sh_a[t]; tile_b[ntiles] = sh_b[t]; }
 }
 
-static __global__ void k_msm_scan_add(uint32_t nbk, uint32_t ntiles, const uint32_t *__restrict__ tile_a,
+template <class C>
+__global__ void
+k_msm_scan_add(uint32_t nbk, uint32_t ntiles, const uint32_t *__restrict__ tile_a,
                                       const uint32_t *__restrict__ tile_b, uint32_t *__restrict__ off,
                                       uint32_t *__restrict__ segoff, uint32_t *__restrict__ cursor) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -102,7 +108,9 @@ static __global__ void k_msm_scan_add(uint32_t nbk, uint32_t ntiles, const uint3
     if (b == nbk) { off[nbk] = tile_a[ntiles]; segoff[nbk] = tile_b[ntiles]; }
 }
 
-static __global__ void k_msm_scatter(const uint32_t *__restrict__ keys, uint32_t n, uint32_t c, uint32_t W,
+template <class C>
+__global__ void
+k_msm_scatter(const uint32_t *__restrict__ keys, uint32_t n, uint32_t c, uint32_t W,
                               const uint32_t *__restrict__ off, uint32_t *__restrict__ cursor,
                               uint32_t *__restrict__ sorted) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -251,14 +259,14 @@ int MsmWork<C>::enqueue(const typename C::Affine *bases, const fe *scalars, cons
         const uint32_t K = nb < MSM_GROUP ? nb : MSM_GROUP, gpw = nb / K;
         ZK_HIP(hipMemsetAsync(hist, 0, sizeof(uint32_t) * (nbk + 1), st));
         ZK_HIP(hipMemsetAsync(heavy_count, 0, sizeof(uint32_t), st));
-        if (n) ZK_LAUNCH(k_msm_digits, zk_div_up(n, 256), 256, st, scalars, gather, n, canonical, c, W, keys, hist);
+        if (n) ZK_LAUNCH(k_msm_digits<C>, zk_div_up(n, 256), 256, st, scalars, gather, n, canonical, c, W, keys, hist);
         {
             const uint32_t ntiles = zk_div_up(nbk, SCAN_TILE);
-            ZK_LAUNCH_SYNC(k_msm_scan_local, ntiles, SCAN_THREADS, st, (const uint32_t *)hist, nbk, off, segoff, tile_a, tile_b);
-            ZK_LAUNCH_SYNC(k_msm_scan_totals, 1, 1024, st, tile_a, tile_b, ntiles);
-            ZK_LAUNCH(k_msm_scan_add, zk_div_up(nbk + 1, 256), 256, st, nbk, ntiles, (const uint32_t *)tile_a, (const uint32_t *)tile_b, off, segoff, cursor);
+            ZK_LAUNCH_SYNC(k_msm_scan_local<C>, ntiles, SCAN_THREADS, st, (const uint32_t *)hist, nbk, off, segoff, tile_a, tile_b);
+            ZK_LAUNCH_SYNC(k_msm_scan_totals<C>, 1, 1024, st, tile_a, tile_b, ntiles);
+            ZK_LAUNCH(k_msm_scan_add<C>, zk_div_up(nbk + 1, 256), 256, st, nbk, ntiles, (const uint32_t *)tile_a, (const uint32_t *)tile_b, off, segoff, cursor);
         }
-        if (n) ZK_LAUNCH(k_msm_scatter, zk_div_up(n, 256), 256, st, (const uint32_t *)keys, n, c, W, (const uint32_t *)off, cursor, sorted);
+        if (n) ZK_LAUNCH(k_msm_scatter<C>, zk_div_up(n, 256), 256, st, (const uint32_t *)keys, n, c, W, (const uint32_t *)off, cursor, sorted);
         // segment count is only known on the device: launch for the upper bound, threads past segoff[nbk] exit
         const uint64_t max_seg = (uint64_t)n * W / MSM_SEG + nbk + 1;
         ZK_HIP(hipEventRecord(ev_acc0, st));
