@@ -7,29 +7,34 @@
 // BDLO12 is the bucket (Pippenger) method; the group element it returns is unique, so any schedule
 // of the additions gives the same proof bytes.
 //
-// GPU schedule (all integer VALU work, random 64/128-B base gathers from HBM):
-//   1 k_msm_digits      scalar -> canonical -> signed c-bit digits; per-(window,bucket) histogram
-//   2 k_msm_scan_*      exclusive scans: entries per bucket, and fixed-length *segments* per bucket
-//   3 k_msm_scatter     counting-sort scatter of (base index, sign) by bucket
-//   4 k_msm_accumulate  one thread per segment (<= SEG entries): XYZZ mixed additions
-//   5 k_msm_bucket_finalize / k_msm_heavy   segments -> bucket sums (heavy buckets by a workgroup)
-//   6 k_msm_group_reduce   running-sum over K buckets + small-scalar offset -> partial window sums
-//   7 k_msm_sum_groups  (x passes) partials -> one XYZZ sum per window
-// The c-bit window shifts (Horner over <= 128 window sums) and the affine normalisation are O(W)
-// sequential group operations and run on the host from the same bn254.hpp.
-// Zero scalars produce no entries; scalar 1 (and any other repeated value) lands in one bucket whose
-// entries are cut into segments, so 0/1-heavy witnesses (the *_with_mixed_addition fast paths of the
-// reference) stay load-balanced without special cases.
+// MI355X-first layout: the query bases are static, HBM is 288 GB, so at context creation every base
+// P_k is expanded to its W window multiples  T[w][k] = 2^(c*w) * P_k  (affine, W*n points: 1 GB per G1
+// query at n = 2^20, c = 16).  A signed digit d of window w of scalar k then contributes sign(d) * T[w][k]
+// to bucket |d| of ONE shared set of 2^(c-1) buckets: no per-window bucket sets, no window Horner,
+// 16x fewer buckets to reduce, ~n*W/2^(c-1) entries per bucket so fixed-length segments are full.
+//
+// Per proof (integer VALU work; random 64/128-B gathers from the table):
+//   1 k_msm_digits      scalar -> canonical -> signed c-bit digits; bucket histogram
+//   2 k_msm_scan_*      exclusive scans: entries per bucket, fixed-length *segments* per bucket
+//   3 k_msm_scatter     counting-sort scatter of (table index, sign) by bucket
+//   4 k_msm_accumulate  one thread per segment: XYZZ mixed additions            <- dominant kernel
+//   5 k_msm_bucket_finalize / k_msm_heavy   segment sums -> bucket sums
+//   6 k_msm_group_reduce   sum_b (b+1) * B_b over groups of buckets (running sums + small offset multiple)
+//   7 k_msm_tree_sum    LDS tree over the group partials -> the MSM result (one XYZZ point)
+// Zero scalars produce no entries; scalar 1 (and any repeated value) lands in one bucket whose entries
+// are cut into segments, so 0/1-heavy witnesses (the *_with_mixed_addition fast paths of the reference)
+// stay load-balanced without special cases; buckets with very many segments go to a workgroup reducer.
 #pragma once
 #include "bn254.hpp"
 #include "common.hpp"
 
 namespace zk {
 
-constexpr uint32_t MSM_SEG = 32;          // entries per accumulation thread
-constexpr uint32_t MSM_HEAVY = 32;        // buckets with more segments than this are reduced by a workgroup
-constexpr uint32_t MSM_GROUP = 16;        // buckets per running-sum thread
-constexpr uint32_t MSM_SUMW = 16;         // fan-in of the partial-sum passes
+constexpr uint32_t MSM_SEG_MIN = 32;      // entries per accumulation thread (lower bound)
+constexpr uint32_t MSM_SEG_PER_BUCKET = 16;   // target segments per bucket (sets the segment length)
+constexpr uint32_t MSM_HEAVY = 64;        // buckets with more segments than this are reduced by a workgroup
+constexpr uint32_t MSM_GROUP = 8;         // buckets per running-sum thread
+constexpr uint32_t MSM_TREE = 256;        // fan-in (= workgroup size) of the final tree sum
 constexpr uint32_t MSM_KEY_NONE = 0xffffffffu;
 #ifdef ZK_EMUL
 constexpr uint32_t MSM_HEAVY_GRID = 2;    // the emulator spawns a real thread per GPU thread
@@ -37,50 +42,45 @@ constexpr uint32_t MSM_HEAVY_GRID = 2;    // the emulator spawns a real thread p
 constexpr uint32_t MSM_HEAVY_GRID = 256;
 #endif
 
-// -------------------------------------------------------------------------------------------------
 struct MsmShape {
-    uint32_t n = 0, c = 0, W = 0, nb = 0, nbk = 0;
+    uint32_t n = 0, c = 0, W = 0, nb = 0, seg = MSM_SEG_MIN;
+    // largest window with >= 32 entries per bucket on average (n * W entries over 2^(c-1) buckets)
     static uint32_t pick_c(uint32_t n) {
-        // accumulate ~ n*W mixed adds, reduce ~ W*2^(c-1) full adds on few threads: keep buckets well below n/8
-        uint32_t c = 2;
-        while (c < 16 && (1ull << (c + 4)) <= (uint64_t)n) c++;
-        return c;
+        for (uint32_t c = 16; c > 2; c--)
+            if ((uint64_t)n * (254 / c + 1) >= ((uint64_t)MSM_SEG_MIN << (c - 1))) return c;
+        return 2;
     }
     void set(uint32_t n_, uint32_t c_) {
         n = n_; c = c_ ? c_ : pick_c(n_);
         if (c < 2) c = 2;
         if (c > 20) c = 20;
-        W = 254 / c + 1; nb = 1u << (c - 1); nbk = W * nb;
+        W = 254 / c + 1; nb = 1u << (c - 1);
+        seg = MSM_SEG_MIN;
+        while (seg < 4096 && (uint64_t)seg * nb * MSM_SEG_PER_BUCKET < max_entries()) seg <<= 1;
     }
     uint64_t max_entries() const { return (uint64_t)n * W; }
-    uint64_t max_segments() const { return max_entries() / MSM_SEG + nbk + 1; }
+    uint64_t max_segments() const { return max_entries() / seg + nb + 1; }
 };
 
 template <class C>
 struct MsmWork {
     MsmShape sh;
+    typename C::Affine *table = nullptr;        // [W][table_n] window multiples of the bases, resident for the context's life
+    uint32_t table_n = 0;
     uint32_t *keys = nullptr, *hist = nullptr, *off = nullptr, *segoff = nullptr, *cursor = nullptr, *sorted = nullptr;
     uint32_t *heavy_list = nullptr, *heavy_count = nullptr, *tile_a = nullptr, *tile_b = nullptr;
     typename C::XYZZ *segsum = nullptr, *bucket = nullptr, *partial_a = nullptr, *partial_b = nullptr;
-    typename C::XYZZ *host_windows = nullptr;   // pinned, W entries
+    typename C::XYZZ *host_result = nullptr;    // pinned, 1 entry
     hipEvent_t ev_acc0 = nullptr, ev_acc1 = nullptr;   // bracket k_msm_accumulate (the dominant kernel) on its stream
     float accumulate_ms() const { float ms = 0; if (ev_acc0 && ev_acc1) hipEventElapsedTime(&ms, ev_acc0, ev_acc1); return ms; }
 
     int alloc(uint32_t n, uint32_t c);
     void release();
-    // enqueue the whole MSM on `st`; window sums land in host_windows after the stream drains
-    int enqueue(const typename C::Affine *bases, const fe *scalars, const uint32_t *gather, uint32_t n,
-                int canonical, hipStream_t st);
-
-    // host: Horner over the window sums (after the stream has been synchronised)
-    typename C::XYZZ finish() const {
-        typename C::XYZZ acc = C::infinity();
-        for (int w = (int)sh.W - 1; w >= 0; w--) {
-            for (uint32_t k = 0; k < sh.c; k++) acc = C::dbl(acc);
-            acc = C::add(acc, host_windows[w]);
-        }
-        return acc;
-    }
+    // table <- window multiples of d_bases[0..n) (device pointer); once per context
+    int precompute(const typename C::Affine *d_bases, uint32_t n, hipStream_t st);
+    // enqueue the whole MSM on `st`; the result lands in host_result after the stream drains
+    int enqueue(const fe *scalars, const uint32_t *gather, uint32_t n, int canonical, hipStream_t st);
+    typename C::XYZZ finish() const { return *host_result; }
 };
 
 }  // namespace zk

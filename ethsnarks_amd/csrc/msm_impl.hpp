@@ -1,17 +1,33 @@
 // msm_impl.hpp -- kernels and launch code of the multi-scalar multiplication (see msm.hpp for the
 // schedule and the reference call sites).  Included only by msm_g1.cpp / msm_g2.cpp, which instantiate
-// MsmWork<G1> / MsmWork<G2> so that the two curve instantiations compile in parallel.
+// MsmWork<G1> / MsmWork<G2> so that the two curve instantiations compile in parallel.  Kernels that do
+// not depend on the curve are still templated on it so that each translation unit owns its symbols.
 #pragma once
 #include "msm.hpp"
 
 namespace zk {
 
+// T[w][k] = 2^(c*w) * P_k, affine; thread per base (one-off, at context creation)
+template <class C>
+__global__ void __launch_bounds__(64, C::WAVES_PER_SIMD)
+k_msm_precompute(const typename C::Affine *__restrict__ bases, uint32_t n, uint32_t c, uint32_t W,
+                 typename C::Affine *__restrict__ table) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const typename C::Affine p = bases[k];
+    table[k] = p;
+    typename C::XYZZ cur = C::from_affine(p);
+    for (uint32_t w = 1; w < W; w++) {
+        for (uint32_t j = 0; j < c; j++) cur = C::dbl(cur);
+        table[(size_t)w * n + k] = C::to_affine(cur);
+    }
+}
+
 // scalar i of this MSM = scalars[gather ? gather[i] : i]; Montgomery unless canonical != 0
 template <class C>
 __global__ void
 k_msm_digits(const fe *__restrict__ scalars, const uint32_t *__restrict__ gather, uint32_t n,
-                             int canonical, uint32_t c, uint32_t W, uint32_t *__restrict__ keys,
-                             uint32_t *__restrict__ hist) {
+             int canonical, uint32_t c, uint32_t W, uint32_t *__restrict__ keys, uint32_t *__restrict__ hist) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     fe s = scalars[gather ? gather[i] : i];
@@ -20,20 +36,16 @@ k_msm_digits(const fe *__restrict__ scalars, const uint32_t *__restrict__ gather
     uint32_t carry = 0;
     for (uint32_t w = 0; w < W; w++) {
         uint32_t bit = w * c, limb = bit >> 5, off = bit & 31;
-        uint32_t d = 0;
-        {
-            uint32_t lo = 0, hi = 0;                            // static selects: keeps the scalar in VGPRs
+        uint32_t lo = 0, hi = 0;                                // static selects: keeps the scalar in VGPRs
 #pragma unroll
-            for (uint32_t k = 0; k < 8; k++) { if (k == limb) lo = s.l[k]; if (k == limb + 1) hi = s.l[k]; }
-            uint64_t v = lo | ((uint64_t)hi << 32);
-            d = (uint32_t)(v >> off) & (full - 1);
-        }
-        d += carry;
+        for (uint32_t k = 0; k < 8; k++) { if (k == limb) lo = s.l[k]; if (k == limb + 1) hi = s.l[k]; }
+        uint64_t v = lo | ((uint64_t)hi << 32);
+        uint32_t d = ((uint32_t)(v >> off) & (full - 1)) + carry;
         uint32_t neg = 0;
         carry = 0;
         if (d > nb) { d = full - d; neg = 1; carry = 1; }     // digit in [-2^(c-1)+1, 2^(c-1)]
         uint32_t key = MSM_KEY_NONE;
-        if (d) { key = (d - 1) | (neg << 31); atomicAdd(&hist[w * nb + d - 1], 1u); }
+        if (d) { key = (d - 1) | (neg << 31); atomicAdd(&hist[d - 1], 1u); }
         keys[(size_t)w * n + i] = key;
     }
 }
@@ -47,7 +59,7 @@ constexpr uint32_t SCAN_THREADS = 256, SCAN_PER_THREAD = 8, SCAN_TILE = SCAN_THR
 
 template <class C>
 __global__ void __launch_bounds__(SCAN_THREADS)
-k_msm_scan_local(const uint32_t *__restrict__ hist, uint32_t nbk, uint32_t *__restrict__ off, uint32_t *__restrict__ segoff,
+k_msm_scan_local(const uint32_t *__restrict__ hist, uint32_t nbk, uint32_t seg, uint32_t *__restrict__ off, uint32_t *__restrict__ segoff,
                  uint32_t *__restrict__ tile_a, uint32_t *__restrict__ tile_b) {
     __shared__ uint32_t sh_a[SCAN_THREADS], sh_b[SCAN_THREADS];
     const uint32_t t = threadIdx.x, b0 = blockIdx.x * SCAN_TILE + t * SCAN_PER_THREAD;
@@ -55,7 +67,7 @@ k_msm_scan_local(const uint32_t *__restrict__ hist, uint32_t nbk, uint32_t *__re
 #pragma unroll
     for (uint32_t k = 0; k < SCAN_PER_THREAD; k++) {
         h[k] = (b0 + k < nbk) ? hist[b0 + k] : 0u;
-        sa += h[k]; sb += (h[k] + MSM_SEG - 1) / MSM_SEG;
+        sa += h[k]; sb += (h[k] + seg - 1) / seg;
     }
     sh_a[t] = sa; sh_b[t] = sb;
     __syncthreads();
@@ -70,7 +82,7 @@ k_msm_scan_local(const uint32_t *__restrict__ hist, uint32_t nbk, uint32_t *__re
 #pragma unroll
     for (uint32_t k = 0; k < SCAN_PER_THREAD; k++) {
         if (b0 + k < nbk) { off[b0 + k] = ea; segoff[b0 + k] = eb; }
-        ea += h[k]; eb += (h[k] + MSM_SEG - 1) / MSM_SEG;
+        ea += h[k]; eb += (h[k] + seg - 1) / seg;
     }
     if (t == SCAN_THREADS - 1) { tile_a[blockIdx.x] = sh_a[t]; tile_b[blockIdx.x] = sh_b[t]; }
 }
@@ -110,39 +122,37 @@ k_msm_scan_add(uint32_t nbk, uint32_t ntiles, const uint32_t *__restrict__ tile_
 
 template <class C>
 __global__ void
-k_msm_scatter(const uint32_t *__restrict__ keys, uint32_t n, uint32_t c, uint32_t W,
-                              const uint32_t *__restrict__ off, uint32_t *__restrict__ cursor,
-                              uint32_t *__restrict__ sorted) {
+k_msm_scatter(const uint32_t *__restrict__ keys, uint32_t n, uint32_t W, const uint32_t *__restrict__ off,
+              uint32_t *__restrict__ cursor, uint32_t *__restrict__ sorted) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t nb = 1u << (c - 1);
     for (uint32_t w = 0; w < W; w++) {
         uint32_t key = keys[(size_t)w * n + i];
         if (key == MSM_KEY_NONE) continue;
-        uint32_t b = w * nb + (key & 0x7fffffffu);
+        uint32_t b = key & 0x7fffffffu;
         uint32_t pos = off[b] + atomicAdd(&cursor[b], 1u);
-        sorted[pos] = i | (key & 0x80000000u);
+        sorted[pos] = (w * n + i) | (key & 0x80000000u);        // table index of 2^(cw) P_i, sign of the digit
     }
 }
 
-// thread per segment; the segment -> bucket map is a binary search in segoff[] (nbk + 1 entries)
+// thread per segment; the segment -> bucket map is a binary search in segoff[] (nb + 1 entries)
 template <class C>
 __global__ void __launch_bounds__(64, C::WAVES_PER_SIMD)
-k_msm_accumulate(const typename C::Affine *__restrict__ bases, const uint32_t *__restrict__ sorted,
-                                 const uint32_t *__restrict__ off, const uint32_t *__restrict__ segoff, uint32_t nbk,
-                                 typename C::XYZZ *__restrict__ segsum) {
+k_msm_accumulate(const typename C::Affine *__restrict__ table, const uint32_t *__restrict__ sorted,
+                 const uint32_t *__restrict__ off, const uint32_t *__restrict__ segoff, uint32_t nb, uint32_t seg,
+                 typename C::XYZZ *__restrict__ segsum) {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t nseg = segoff[nbk];
+    const uint32_t nseg = segoff[nb];
     if (s >= nseg) return;
-    uint32_t lo = 0, hi = nbk;                                 // largest b with segoff[b] <= s
+    uint32_t lo = 0, hi = nb;                                  // largest b with segoff[b] <= s
     while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (segoff[mid] <= s) lo = mid; else hi = mid; }
     const uint32_t b = lo;
-    uint32_t begin = off[b] + (s - segoff[b]) * MSM_SEG, end = begin + MSM_SEG;
+    uint32_t begin = off[b] + (s - segoff[b]) * seg, end = begin + seg;
     if (end > off[b + 1]) end = off[b + 1];
     typename C::XYZZ acc = C::infinity();
     for (uint32_t e = begin; e < end; e++) {
         uint32_t p = sorted[e];
-        typename C::Affine q = bases[p & 0x7fffffffu];
+        typename C::Affine q = table[p & 0x7fffffffu];
         if (p >> 31) q = C::neg(q);
         acc = C::madd(acc, q);
     }
@@ -153,10 +163,10 @@ k_msm_accumulate(const typename C::Affine *__restrict__ bases, const uint32_t *_
 template <class C>
 __global__ void __launch_bounds__(64, C::WAVES_PER_SIMD)
 k_msm_bucket_finalize(const typename C::XYZZ *__restrict__ segsum, const uint32_t *__restrict__ segoff,
-                                      uint32_t nbk, typename C::XYZZ *__restrict__ bucket,
-                                      uint32_t *__restrict__ heavy_list, uint32_t *__restrict__ heavy_count) {
+                      uint32_t nb, typename C::XYZZ *__restrict__ bucket,
+                      uint32_t *__restrict__ heavy_list, uint32_t *__restrict__ heavy_count) {
     uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nbk) return;
+    if (b >= nb) return;
     uint32_t s0 = segoff[b], s1 = segoff[b + 1];
     if (s1 - s0 > MSM_HEAVY) { heavy_list[atomicAdd(heavy_count, 1u)] = b; return; }
     typename C::XYZZ acc = C::infinity();
@@ -187,109 +197,117 @@ k_msm_heavy(const typename C::XYZZ *__restrict__ segsum, const uint32_t *__restr
     }
 }
 
-// thread per group of MSM_GROUP buckets of one window:  sum_j (g*K + j + 1) * B_j
+// thread per group of K consecutive buckets:  sum_j (g*K + j + 1) * B_{g*K+j}
 template <class C>
 __global__ void __launch_bounds__(64, C::WAVES_PER_SIMD)
-k_msm_group_reduce(const typename C::XYZZ *__restrict__ bucket, uint32_t c, uint32_t W,
-                                   typename C::XYZZ *__restrict__ partial) {
-    const uint32_t nb = 1u << (c - 1);
-    const uint32_t K = nb < MSM_GROUP ? nb : MSM_GROUP, gpw = nb / K;
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= W * gpw) return;
-    const uint32_t w = t / gpw, g = t - w * gpw;
-    const typename C::XYZZ *B = bucket + (size_t)w * nb + (size_t)g * K;
+k_msm_group_reduce(const typename C::XYZZ *__restrict__ bucket, uint32_t nb, uint32_t K,
+                   typename C::XYZZ *__restrict__ partial) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= nb / K) return;
+    const typename C::XYZZ *B = bucket + (size_t)g * K;
     typename C::XYZZ run = C::infinity(), acc = C::infinity();
     for (uint32_t j = K; j-- > 0;) { run = C::add(run, B[j]); acc = C::add(acc, run); }
     if (g) acc = C::add(acc, C::mul_small(run, g * K));
-    partial[t] = acc;
+    partial[g] = acc;
 }
 
-// out[o] = sum_{i < fan} in[o * fan + i]  (i bounded by per_out_total), contiguous groups
+// out[blockIdx] = sum of in[blockIdx*256 .. +256) (bounded by count): LDS tree, upper half parks
 template <class C>
-__global__ void __launch_bounds__(64, C::WAVES_PER_SIMD)
-k_msm_sum_groups(const typename C::XYZZ *__restrict__ in, uint32_t n_in_per_window, uint32_t fan,
-                                 uint32_t n_out_per_window, uint32_t W, typename C::XYZZ *__restrict__ out) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= W * n_out_per_window) return;
-    const uint32_t w = t / n_out_per_window, o = t - w * n_out_per_window;
-    uint32_t i0 = o * fan, i1 = i0 + fan;
-    if (i1 > n_in_per_window) i1 = n_in_per_window;
-    typename C::XYZZ acc = C::infinity();
-    for (uint32_t i = i0; i < i1; i++) acc = C::add(acc, in[(size_t)w * n_in_per_window + i]);
-    out[t] = acc;
+__global__ void __launch_bounds__(MSM_TREE)
+k_msm_tree_sum(const typename C::XYZZ *__restrict__ in, uint32_t count, typename C::XYZZ *__restrict__ out) {
+    __shared__ typename C::XYZZ sh[MSM_TREE / 2];
+    const uint32_t i = blockIdx.x * MSM_TREE + threadIdx.x;
+    typename C::XYZZ acc = i < count ? in[i] : C::infinity();
+    for (uint32_t half = MSM_TREE / 2; half > 0; half >>= 1) {
+        if (threadIdx.x >= half && threadIdx.x < 2 * half) sh[threadIdx.x - half] = acc;
+        __syncthreads();
+        if (threadIdx.x < half) acc = C::add(acc, sh[threadIdx.x]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = acc;
 }
 
+// -------------------------------------------------------------------------------------------------
 template <class C>
 int MsmWork<C>::alloc(uint32_t n, uint32_t c) {
-        sh.set(n ? n : 1, c);
-        const uint32_t K = sh.nb < MSM_GROUP ? sh.nb : MSM_GROUP;
-        ZK_HIP(hipMalloc(&keys, sizeof(uint32_t) * sh.max_entries()));
-        ZK_HIP(hipMalloc(&sorted, sizeof(uint32_t) * sh.max_entries()));
-        ZK_HIP(hipMalloc(&hist, sizeof(uint32_t) * (sh.nbk + 1)));
-        ZK_HIP(hipMalloc(&off, sizeof(uint32_t) * (sh.nbk + 1)));
-        ZK_HIP(hipMalloc(&segoff, sizeof(uint32_t) * (sh.nbk + 1)));
-        ZK_HIP(hipMalloc(&cursor, sizeof(uint32_t) * (sh.nbk + 1)));
-        ZK_HIP(hipMalloc(&heavy_list, sizeof(uint32_t) * (sh.max_entries() / (MSM_SEG * MSM_HEAVY) + 2)));
-        ZK_HIP(hipMalloc(&heavy_count, sizeof(uint32_t)));
-        ZK_HIP(hipMalloc(&tile_a, sizeof(uint32_t) * (zk_div_up(sh.nbk, SCAN_TILE) + 1)));
-        ZK_HIP(hipMalloc(&tile_b, sizeof(uint32_t) * (zk_div_up(sh.nbk, SCAN_TILE) + 1)));
-        ZK_HIP(hipMalloc(&segsum, sizeof(typename C::XYZZ) * sh.max_segments()));
-        ZK_HIP(hipMalloc(&bucket, sizeof(typename C::XYZZ) * sh.nbk));
-        ZK_HIP(hipMalloc(&partial_a, sizeof(typename C::XYZZ) * (size_t)sh.W * (sh.nb / K)));
-        ZK_HIP(hipMalloc(&partial_b, sizeof(typename C::XYZZ) * (size_t)sh.W * (sh.nb / K / MSM_SUMW + 1)));
-        ZK_HIP(hipHostMalloc(&host_windows, sizeof(typename C::XYZZ) * sh.W, hipHostMallocDefault));
-        ZK_HIP(hipEventCreate(&ev_acc0)); ZK_HIP(hipEventCreate(&ev_acc1));
-        return ZK_OK;
-    }
+    sh.set(n ? n : 1, c);
+    const uint32_t K = sh.nb < MSM_GROUP ? sh.nb : MSM_GROUP, groups = sh.nb / K;
+    ZK_HIP(hipMalloc(&table, sizeof(typename C::Affine) * sh.max_entries()));
+    ZK_HIP(hipMalloc(&keys, sizeof(uint32_t) * sh.max_entries()));
+    ZK_HIP(hipMalloc(&sorted, sizeof(uint32_t) * sh.max_entries()));
+    ZK_HIP(hipMalloc(&hist, sizeof(uint32_t) * (sh.nb + 1)));
+    ZK_HIP(hipMalloc(&off, sizeof(uint32_t) * (sh.nb + 1)));
+    ZK_HIP(hipMalloc(&segoff, sizeof(uint32_t) * (sh.nb + 1)));
+    ZK_HIP(hipMalloc(&cursor, sizeof(uint32_t) * (sh.nb + 1)));
+    ZK_HIP(hipMalloc(&heavy_list, sizeof(uint32_t) * (sh.max_entries() / ((uint64_t)sh.seg * MSM_HEAVY) + 2)));
+    ZK_HIP(hipMalloc(&heavy_count, sizeof(uint32_t)));
+    ZK_HIP(hipMalloc(&tile_a, sizeof(uint32_t) * (zk_div_up(sh.nb, SCAN_TILE) + 1)));
+    ZK_HIP(hipMalloc(&tile_b, sizeof(uint32_t) * (zk_div_up(sh.nb, SCAN_TILE) + 1)));
+    ZK_HIP(hipMalloc(&segsum, sizeof(typename C::XYZZ) * sh.max_segments()));
+    ZK_HIP(hipMalloc(&bucket, sizeof(typename C::XYZZ) * sh.nb));
+    ZK_HIP(hipMalloc(&partial_a, sizeof(typename C::XYZZ) * (groups + 1)));
+    ZK_HIP(hipMalloc(&partial_b, sizeof(typename C::XYZZ) * (zk_div_up(groups, MSM_TREE) + 1)));
+    ZK_HIP(hipHostMalloc(&host_result, sizeof(typename C::XYZZ), hipHostMallocDefault));
+    ZK_HIP(hipEventCreate(&ev_acc0)); ZK_HIP(hipEventCreate(&ev_acc1));
+    return ZK_OK;
+}
+
 template <class C>
 void MsmWork<C>::release() {
-        void *dev[] = {keys, hist, off, segoff, cursor, sorted, heavy_list, heavy_count, tile_a, tile_b, segsum, bucket, partial_a, partial_b};
-        for (void *p : dev) if (p) hipFree(p);
-        if (host_windows) hipHostFree(host_windows);
-        if (ev_acc0) hipEventDestroy(ev_acc0);
-        if (ev_acc1) hipEventDestroy(ev_acc1);
-        *this = MsmWork();
-    }
+    void *dev[] = {table, keys, hist, off, segoff, cursor, sorted, heavy_list, heavy_count, tile_a, tile_b, segsum, bucket, partial_a, partial_b};
+    for (void *p : dev) if (p) hipFree(p);
+    if (host_result) hipHostFree(host_result);
+    if (ev_acc0) hipEventDestroy(ev_acc0);
+    if (ev_acc1) hipEventDestroy(ev_acc1);
+    *this = MsmWork();
+}
 
 template <class C>
-int MsmWork<C>::enqueue(const typename C::Affine *bases, const fe *scalars, const uint32_t *gather, uint32_t n,
-                int canonical, hipStream_t st) {
-        if (n > sh.n) return ZK_ERR_ARG;
-        const uint32_t c = sh.c, W = sh.W, nb = sh.nb, nbk = sh.nbk;
-        const uint32_t K = nb < MSM_GROUP ? nb : MSM_GROUP, gpw = nb / K;
-        ZK_HIP(hipMemsetAsync(hist, 0, sizeof(uint32_t) * (nbk + 1), st));
-        ZK_HIP(hipMemsetAsync(heavy_count, 0, sizeof(uint32_t), st));
-        if (n) ZK_LAUNCH(k_msm_digits<C>, zk_div_up(n, 256), 256, st, scalars, gather, n, canonical, c, W, keys, hist);
-        {
-            const uint32_t ntiles = zk_div_up(nbk, SCAN_TILE);
-            ZK_LAUNCH_SYNC(k_msm_scan_local<C>, ntiles, SCAN_THREADS, st, (const uint32_t *)hist, nbk, off, segoff, tile_a, tile_b);
-            ZK_LAUNCH_SYNC(k_msm_scan_totals<C>, 1, 1024, st, tile_a, tile_b, ntiles);
-            ZK_LAUNCH(k_msm_scan_add<C>, zk_div_up(nbk + 1, 256), 256, st, nbk, ntiles, (const uint32_t *)tile_a, (const uint32_t *)tile_b, off, segoff, cursor);
-        }
-        if (n) ZK_LAUNCH(k_msm_scatter<C>, zk_div_up(n, 256), 256, st, (const uint32_t *)keys, n, c, W, (const uint32_t *)off, cursor, sorted);
-        // segment count is only known on the device: launch for the upper bound, threads past segoff[nbk] exit
-        const uint64_t max_seg = (uint64_t)n * W / MSM_SEG + nbk + 1;
-        ZK_HIP(hipEventRecord(ev_acc0, st));
-        ZK_LAUNCH(k_msm_accumulate<C>, zk_div_up(max_seg, 64), 64, st, bases, (const uint32_t *)sorted,
-                  (const uint32_t *)off, (const uint32_t *)segoff, nbk, segsum);
-        ZK_HIP(hipEventRecord(ev_acc1, st));
-        ZK_LAUNCH(k_msm_bucket_finalize<C>, zk_div_up(nbk, 64), 64, st, (const typename C::XYZZ *)segsum,
-                  (const uint32_t *)segoff, nbk, bucket, heavy_list, heavy_count);
-        ZK_LAUNCH_SYNC(k_msm_heavy<C>, MSM_HEAVY_GRID, 128, st, (const typename C::XYZZ *)segsum, (const uint32_t *)segoff,
-                       (const uint32_t *)heavy_list, (const uint32_t *)heavy_count, bucket);
-        ZK_LAUNCH(k_msm_group_reduce<C>, zk_div_up((uint64_t)W * gpw, 64), 64, st, (const typename C::XYZZ *)bucket, c, W, partial_a);
-        typename C::XYZZ *cur = partial_a, *nxt = partial_b;
-        uint32_t per = gpw;
-        while (per > 1) {
-            uint32_t outp = zk_div_up(per, MSM_SUMW);
-            ZK_LAUNCH(k_msm_sum_groups<C>, zk_div_up((uint64_t)W * outp, 64), 64, st, (const typename C::XYZZ *)cur, per, MSM_SUMW, outp, W, nxt);
-            typename C::XYZZ *t = cur; cur = nxt; nxt = t;
-            per = outp;
-        }
-        ZK_HIP(hipGetLastError());
-        ZK_HIP(hipMemcpyAsync(host_windows, cur, sizeof(typename C::XYZZ) * W, hipMemcpyDeviceToHost, st));
-        return ZK_OK;
-    }
+int MsmWork<C>::precompute(const typename C::Affine *d_bases, uint32_t n, hipStream_t st) {
+    if (n > sh.n) return ZK_ERR_ARG;
+    table_n = n;
+    if (n) ZK_LAUNCH(k_msm_precompute<C>, zk_div_up(n, 64), 64, st, d_bases, n, sh.c, sh.W, table);
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+}
 
+template <class C>
+int MsmWork<C>::enqueue(const fe *scalars, const uint32_t *gather, uint32_t n, int canonical, hipStream_t st) {
+    if (n != table_n) return ZK_ERR_ARG;                        // the table stride is the precompute-time n
+    const uint32_t c = sh.c, W = sh.W, nb = sh.nb, seg = sh.seg;
+    const uint32_t K = nb < MSM_GROUP ? nb : MSM_GROUP, groups = nb / K;
+    ZK_HIP(hipMemsetAsync(hist, 0, sizeof(uint32_t) * (nb + 1), st));
+    ZK_HIP(hipMemsetAsync(heavy_count, 0, sizeof(uint32_t), st));
+    if (n) ZK_LAUNCH(k_msm_digits<C>, zk_div_up(n, 256), 256, st, scalars, gather, n, canonical, c, W, keys, hist);
+    {
+        const uint32_t ntiles = zk_div_up(nb, SCAN_TILE);
+        ZK_LAUNCH_SYNC(k_msm_scan_local<C>, ntiles, SCAN_THREADS, st, (const uint32_t *)hist, nb, seg, off, segoff, tile_a, tile_b);
+        ZK_LAUNCH_SYNC(k_msm_scan_totals<C>, 1, 1024, st, tile_a, tile_b, ntiles);
+        ZK_LAUNCH(k_msm_scan_add<C>, zk_div_up(nb + 1, 256), 256, st, nb, ntiles, (const uint32_t *)tile_a, (const uint32_t *)tile_b, off, segoff, cursor);
+    }
+    if (n) ZK_LAUNCH(k_msm_scatter<C>, zk_div_up(n, 256), 256, st, (const uint32_t *)keys, n, W, (const uint32_t *)off, cursor, sorted);
+    // segment count is only known on the device: launch for the upper bound, threads past segoff[nb] exit.
+    const uint64_t max_seg = (uint64_t)n * W / seg + nb + 1;
+    ZK_HIP(hipEventRecord(ev_acc0, st));
+    ZK_LAUNCH(k_msm_accumulate<C>, zk_div_up(max_seg, 64), 64, st, (const typename C::Affine *)table, (const uint32_t *)sorted,
+              (const uint32_t *)off, (const uint32_t *)segoff, nb, seg, segsum);
+    ZK_HIP(hipEventRecord(ev_acc1, st));
+    ZK_LAUNCH(k_msm_bucket_finalize<C>, zk_div_up(nb, 64), 64, st, (const typename C::XYZZ *)segsum,
+              (const uint32_t *)segoff, nb, bucket, heavy_list, heavy_count);
+    ZK_LAUNCH_SYNC(k_msm_heavy<C>, MSM_HEAVY_GRID, 128, st, (const typename C::XYZZ *)segsum, (const uint32_t *)segoff,
+                   (const uint32_t *)heavy_list, (const uint32_t *)heavy_count, bucket);
+    ZK_LAUNCH(k_msm_group_reduce<C>, zk_div_up(groups, 64), 64, st, (const typename C::XYZZ *)bucket, nb, K, partial_a);
+    typename C::XYZZ *cur = partial_a, *nxt = partial_b;
+    uint32_t count = groups;
+    do {
+        uint32_t outc = zk_div_up(count, MSM_TREE);
+        ZK_LAUNCH_SYNC(k_msm_tree_sum<C>, outc, MSM_TREE, st, (const typename C::XYZZ *)cur, count, nxt);
+        typename C::XYZZ *t = cur; cur = nxt; nxt = t;
+        count = outc;
+    } while (count > 1);
+    ZK_HIP(hipGetLastError());
+    ZK_HIP(hipMemcpyAsync(host_result, cur, sizeof(typename C::XYZZ), hipMemcpyDeviceToHost, st));
+    return ZK_OK;
+}
 
 }  // namespace zk

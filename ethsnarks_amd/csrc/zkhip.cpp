@@ -297,7 +297,6 @@ struct zk_ctx {
     G1::Affine alpha_g1; G2::Affine beta_g2;
     // shard-local base ranges (whole query when unsharded)
     Range rA{}, rB{}, rH{}, rL{};
-    G1::Affine *dA = nullptr, *dH = nullptr, *dL = nullptr; G2::Affine *dB = nullptr;
     uint32_t *dA_idx = nullptr, *dB_idx = nullptr;
     DevCsr cA, cB, cC;
     fe *d_w = nullptr, *d_a = nullptr, *d_b = nullptr, *d_c = nullptr, *d_t = nullptr;
@@ -310,7 +309,7 @@ struct zk_ctx {
                ev_l0 = nullptr, ev_l1 = nullptr, ev_h1 = nullptr;
     ~zk_ctx() {
         hipSetDevice(device);
-        void *dev[] = {dA, dH, dL, dB, dA_idx, dB_idx, d_w, d_a, d_b, d_c, d_t};
+        void *dev[] = {dA_idx, dB_idx, d_w, d_a, d_b, d_c, d_t};
         for (void *p : dev) if (p) hipFree(p);
         if (h_w) hipHostFree(h_w);
         if (h_tail) hipHostFree(h_tail);
@@ -339,12 +338,29 @@ static int ctx_build(zk_ctx *c, const zk_pk *pk, const zk_csr *A, const zk_csr *
     c->rB = shard_range((uint32_t)pk->b_val.size(), r, G);
     c->rH = shard_range(m - 1, r, G);
     c->rL = shard_range(V - nIn, r, G);
-    ZK_TRY(dev_upload(&c->dA, pk->a_val.data() + c->rA.lo, c->rA.n()));
     ZK_TRY(dev_upload(&c->dA_idx, pk->a_idx.data() + c->rA.lo, c->rA.n()));
-    ZK_TRY(dev_upload(&c->dB, pk->b_val.data() + c->rB.lo, c->rB.n()));
     ZK_TRY(dev_upload(&c->dB_idx, pk->b_idx.data() + c->rB.lo, c->rB.n()));
-    ZK_TRY(dev_upload(&c->dH, pk->H.data() + c->rH.lo, c->rH.n()));
-    ZK_TRY(dev_upload(&c->dL, pk->L.data() + c->rL.lo, c->rL.n()));
+    // bases -> window-multiple tables (msm.hpp); the raw affine arrays are only staging
+    {
+        G1::Affine *d1 = nullptr; G2::Affine *d2 = nullptr;
+        auto build1 = [&](MsmWork<G1> &w, const G1::Affine *src, uint32_t n) -> int {
+            ZK_TRY(w.alloc(n, c->cfg.multi_exp_c));
+            ZK_TRY(dev_upload(&d1, src, n));
+            int rc = w.precompute(d1, n, nullptr);
+            if (rc == ZK_OK && hipDeviceSynchronize() != hipSuccess) rc = fail(ZK_ERR_HIP, "k_msm_precompute failed");
+            hipFree(d1); d1 = nullptr;
+            return rc;
+        };
+        ZK_TRY(build1(c->mA, pk->a_val.data() + c->rA.lo, c->rA.n()));
+        ZK_TRY(build1(c->mH, pk->H.data() + c->rH.lo, c->rH.n()));
+        ZK_TRY(build1(c->mL, pk->L.data() + c->rL.lo, c->rL.n()));
+        ZK_TRY(c->mB.alloc(c->rB.n(), c->cfg.multi_exp_c));
+        ZK_TRY(dev_upload(&d2, pk->b_val.data() + c->rB.lo, c->rB.n()));
+        int rc = c->mB.precompute(d2, c->rB.n(), nullptr);
+        if (rc == ZK_OK && hipDeviceSynchronize() != hipSuccess) rc = fail(ZK_ERR_HIP, "k_msm_precompute failed");
+        hipFree(d2);
+        ZK_TRY(rc);
+    }
     ZK_TRY(c->cA.upload(A, V)); ZK_TRY(c->cB.upload(B, V)); ZK_TRY(c->cC.upload(C, V));
     ZK_HIP(hipMalloc(&c->d_w, 32 * (size_t)(V + 1)));
     ZK_HIP(hipMalloc(&c->d_a, 32 * (size_t)m)); ZK_HIP(hipMalloc(&c->d_b, 32 * (size_t)m));
@@ -367,10 +383,6 @@ static int ctx_build(zk_ctx *c, const zk_pk *pk, const zk_csr *A, const zk_csr *
     hipEvent_t *ee[] = {&c->ev_start, &c->ev_w, &c->ev_h, &c->ev_a0, &c->ev_a1, &c->ev_b0, &c->ev_b1, &c->ev_l0, &c->ev_l1, &c->ev_h1};
     for (auto e : ee) ZK_HIP(hipEventCreate(e));
     ZK_TRY(ntt_tables_create(c->tab, c->logm, c->s_main));
-    ZK_TRY(c->mA.alloc(c->rA.n(), c->cfg.multi_exp_c));
-    ZK_TRY(c->mB.alloc(c->rB.n(), c->cfg.multi_exp_c));
-    ZK_TRY(c->mH.alloc(c->rH.n(), c->cfg.multi_exp_c));
-    ZK_TRY(c->mL.alloc(c->rL.n(), c->cfg.multi_exp_c));
     ZK_HIP(hipStreamSynchronize(c->s_main));
     return ZK_OK;
 }
@@ -444,17 +456,17 @@ static int prove_partial_impl(zk_ctx *c, const uint64_t *witness, int canonical,
     ZK_HIP(hipStreamWaitEvent(c->s_b, c->ev_w, 0));
     ZK_HIP(hipStreamWaitEvent(c->s_l, c->ev_w, 0));
     ZK_HIP(hipEventRecord(c->ev_a0, c->s_a));
-    ZK_TRY(c->mA.enqueue(c->dA, c->d_w, c->dA_idx, c->rA.n(), 0, c->s_a));              // tcc:488-495
+    ZK_TRY(c->mA.enqueue(c->d_w, c->dA_idx, c->rA.n(), 0, c->s_a));              // tcc:488-495
     ZK_HIP(hipEventRecord(c->ev_a1, c->s_a));
     ZK_HIP(hipEventRecord(c->ev_b0, c->s_b));
-    ZK_TRY(c->mB.enqueue(c->dB, c->d_w, c->dB_idx, c->rB.n(), 0, c->s_b));              // tcc:499-506
+    ZK_TRY(c->mB.enqueue(c->d_w, c->dB_idx, c->rB.n(), 0, c->s_b));              // tcc:499-506
     ZK_HIP(hipEventRecord(c->ev_b1, c->s_b));
     ZK_HIP(hipEventRecord(c->ev_l0, c->s_l));
-    ZK_TRY(c->mL.enqueue(c->dL, c->d_w + (c->nIn + 1) + c->rL.lo, nullptr, c->rL.n(), 0, c->s_l));   // tcc:522-530
+    ZK_TRY(c->mL.enqueue(c->d_w + (c->nIn + 1) + c->rL.lo, nullptr, c->rL.n(), 0, c->s_l));   // tcc:522-530
     ZK_HIP(hipEventRecord(c->ev_l1, c->s_l));
     ZK_TRY(enqueue_compute_h(c));
     ZK_HIP(hipEventRecord(c->ev_h, c->s_main));
-    ZK_TRY(c->mH.enqueue(c->dH, c->d_t + c->rH.lo, nullptr, c->rH.n(), 0, c->s_main));  // tcc:510-518
+    ZK_TRY(c->mH.enqueue(c->d_t + c->rH.lo, nullptr, c->rH.n(), 0, c->s_main));  // tcc:510-518
     ZK_HIP(hipEventRecord(c->ev_h1, c->s_main));
     ZK_HIP(hipStreamSynchronize(c->s_a)); ZK_HIP(hipStreamSynchronize(c->s_b));
     ZK_HIP(hipStreamSynchronize(c->s_l)); ZK_HIP(hipStreamSynchronize(c->s_main));
@@ -770,7 +782,8 @@ static int msm_host(const uint64_t *bases, const uint64_t *scalars, uint32_t n, 
     int rc = dev_upload(&d_bases, (const typename C::Affine *)bases, n);
     if (rc == ZK_OK) rc = dev_upload(&d_scalars, (const fe *)scalars, n);
     if (rc == ZK_OK) rc = work.alloc(n, cbits);
-    if (rc == ZK_OK) rc = work.enqueue(d_bases, d_scalars, nullptr, n, 0, nullptr);
+    if (rc == ZK_OK) rc = work.precompute(d_bases, n, nullptr);
+    if (rc == ZK_OK) rc = work.enqueue(d_scalars, nullptr, n, 0, nullptr);
     if (rc == ZK_OK && hipDeviceSynchronize() != hipSuccess) rc = fail(ZK_ERR_HIP, "MSM kernels failed");
     if (rc == ZK_OK) {
         typename C::Affine a = C::to_affine(work.finish());
