@@ -15,6 +15,9 @@
 #pragma once
 #include "common.hpp"
 #include <stdint.h>
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZK_NO_ASM)
+#include "fips_asm.hpp"
+#endif
 
 #ifndef ZK_HD
 #define ZK_HD __host__ __device__ __forceinline__
@@ -39,6 +42,7 @@ struct FrParams {
         return v[i];
     }
     static constexpr uint32_t inv = 0xefffffffu;   // -r^-1 mod 2^32
+    static constexpr bool is_fq = false;
 };
 struct FqParams {
     static ZK_HD constexpr uint32_t p(int i) {
@@ -54,6 +58,7 @@ struct FqParams {
         return v[i];
     }
     static constexpr uint32_t inv = 0xe4866389u;   // -q^-1 mod 2^32
+    static constexpr bool is_fq = true;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -77,7 +82,7 @@ struct Field {
         return t == 0;
     }
     // r = a - p if a >= p else a   (a < 2p)
-    static ZK_HD fe reduce_once(const fe &a) {
+    static ZK_HD fe reduce_once_c(const fe &a) {
         fe d; uint64_t br = 0;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
@@ -89,13 +94,13 @@ struct Field {
         for (int i = 0; i < 8; i++) r.l[i] = br ? a.l[i] : d.l[i];
         return r;
     }
-    static ZK_HD fe add(const fe &a, const fe &b) {
+    static ZK_HD fe add_c(const fe &a, const fe &b) {
         fe s; uint64_t c = 0;
 #pragma unroll
         for (int i = 0; i < 8; i++) { c += (uint64_t)a.l[i] + b.l[i]; s.l[i] = (uint32_t)c; c >>= 32; }
-        return reduce_once(s);     // p < 2^254 so a + b < 2^255: no carry out of limb 7
+        return reduce_once_c(s);   // p < 2^254 so a + b < 2^255: no carry out of limb 7
     }
-    static ZK_HD fe sub(const fe &a, const fe &b) {
+    static ZK_HD fe sub_c(const fe &a, const fe &b) {
         fe d; uint64_t br = 0;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
@@ -108,11 +113,34 @@ struct Field {
         for (int i = 0; i < 8; i++) { c += (uint64_t)d.l[i] + (P::p(i) & mask); d.l[i] = (uint32_t)c; c >>= 32; }
         return d;
     }
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZK_NO_ASM)
+    // gfx950 forms: explicit VCC carry chains (hipcc lowers the portable 64-bit arithmetic to ~4x the instructions)
+    static __device__ __forceinline__ fe reduce_once(const fe &a) {
+        fe r = a;
+        if constexpr (P::is_fq) fips::reduce8_fq(r.l); else fips::reduce8_fr(r.l);
+        return r;
+    }
+    static __device__ __forceinline__ fe add(const fe &a, const fe &b) {
+        fe s; fips::add8(s.l, a.l, b.l);
+        if constexpr (P::is_fq) fips::reduce8_fq(s.l); else fips::reduce8_fr(s.l);
+        return s;
+    }
+    static __device__ __forceinline__ fe sub(const fe &a, const fe &b) {
+        fe d; uint32_t mask = fips::sub8(d.l, a.l, b.l);
+        if constexpr (P::is_fq) fips::addp_masked8_fq(d.l, mask); else fips::addp_masked8_fr(d.l, mask);
+        return d;
+    }
+#else
+    static ZK_HD fe reduce_once(const fe &a) { return reduce_once_c(a); }
+    static ZK_HD fe add(const fe &a, const fe &b) { return add_c(a, b); }
+    static ZK_HD fe sub(const fe &a, const fe &b) { return sub_c(a, b); }
+#endif
     static ZK_HD fe neg(const fe &a) { return is_zero(a) ? a : sub(zero(), a); }
     static ZK_HD fe dbl(const fe &a) { return add(a, a); }
 
-    // Montgomery product a*b*R^-1 mod p (CIOS over 32-bit limbs; each step is one v_mad_u64_u32)
-    static ZK_HD fe mul(const fe &a, const fe &b) {
+    // Montgomery product a*b*R^-1 mod p.  Portable form: CIOS over 32-bit limbs (host code and the CPU
+    // emulation harness); device form: mul_fips below.
+    static ZK_HD fe mul_cios(const fe &a, const fe &b) {
         uint32_t t[9];
 #pragma unroll
         for (int i = 0; i < 9; i++) t[i] = 0;
@@ -141,8 +169,76 @@ struct Field {
         fe r;
 #pragma unroll
         for (int i = 0; i < 8; i++) r.l[i] = t[i];
-        return reduce_once(r);                        // result < 2p < 2^255, t[8] == 0
+        return reduce_once_c(r);                      // result < 2p < 2^255, t[8] == 0
     }
+
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZK_NO_ASM)
+    // gfx950 form: finely integrated product scanning.  Column k of a*b + m*p is summed into a 96-bit
+    // accumulator (64-bit VGPR pair + 32-bit carry word): every partial product is ONE v_mad_u64_u32 whose
+    // 64-bit addend is the accumulator itself, plus ONE v_addc_co_u32 that banks the carry-out the mad
+    // leaves in an SGPR pair.  hipcc cannot use that carry-out from C (it builds zero-extended addend pairs
+    // with v_mov / v_lshl_add_u64 instead: 565 VALU instructions per product against ~330 here).
+    // The modulus limbs ride in SGPRs (wave-uniform constants).  VALU-written SGPR carry -> VALU carry-in is
+    // hardware-interlocked on gfx9 (the same pattern hipcc emits through VCC), so no s_nop is needed.
+    // (hi:lo) += sum of the a*b products of column i, then of its m*p products: one asm statement each
+    template <int N, int J0, int I>
+    static __device__ __forceinline__ void col_ab(uint64_t &lo, uint32_t &hi, const fe &a, const fe &b) {
+#define ZK_AB(k) a.l[J0 + k], b.l[I - J0 - k]
+        if constexpr (N == 1) fips::mac1_vv(lo, hi, ZK_AB(0));
+        if constexpr (N == 2) fips::mac2_vv(lo, hi, ZK_AB(0), ZK_AB(1));
+        if constexpr (N == 3) fips::mac3_vv(lo, hi, ZK_AB(0), ZK_AB(1), ZK_AB(2));
+        if constexpr (N == 4) fips::mac4_vv(lo, hi, ZK_AB(0), ZK_AB(1), ZK_AB(2), ZK_AB(3));
+        if constexpr (N == 5) fips::mac5_vv(lo, hi, ZK_AB(0), ZK_AB(1), ZK_AB(2), ZK_AB(3), ZK_AB(4));
+        if constexpr (N == 6) fips::mac6_vv(lo, hi, ZK_AB(0), ZK_AB(1), ZK_AB(2), ZK_AB(3), ZK_AB(4), ZK_AB(5));
+        if constexpr (N == 7) fips::mac7_vv(lo, hi, ZK_AB(0), ZK_AB(1), ZK_AB(2), ZK_AB(3), ZK_AB(4), ZK_AB(5), ZK_AB(6));
+        if constexpr (N == 8) fips::mac8_vv(lo, hi, ZK_AB(0), ZK_AB(1), ZK_AB(2), ZK_AB(3), ZK_AB(4), ZK_AB(5), ZK_AB(6), ZK_AB(7));
+#undef ZK_AB
+    }
+    template <int N, int J0, int I>
+    static __device__ __forceinline__ void col_mp(uint64_t &lo, uint32_t &hi, const uint32_t (&m)[8]) {
+#define ZK_MP(k) m[J0 + k], P::p(I - J0 - k)
+        if constexpr (N == 1) fips::mac1_vs(lo, hi, ZK_MP(0));
+        if constexpr (N == 2) fips::mac2_vs(lo, hi, ZK_MP(0), ZK_MP(1));
+        if constexpr (N == 3) fips::mac3_vs(lo, hi, ZK_MP(0), ZK_MP(1), ZK_MP(2));
+        if constexpr (N == 4) fips::mac4_vs(lo, hi, ZK_MP(0), ZK_MP(1), ZK_MP(2), ZK_MP(3));
+        if constexpr (N == 5) fips::mac5_vs(lo, hi, ZK_MP(0), ZK_MP(1), ZK_MP(2), ZK_MP(3), ZK_MP(4));
+        if constexpr (N == 6) fips::mac6_vs(lo, hi, ZK_MP(0), ZK_MP(1), ZK_MP(2), ZK_MP(3), ZK_MP(4), ZK_MP(5));
+        if constexpr (N == 7) fips::mac7_vs(lo, hi, ZK_MP(0), ZK_MP(1), ZK_MP(2), ZK_MP(3), ZK_MP(4), ZK_MP(5), ZK_MP(6));
+        if constexpr (N == 8) fips::mac8_vs(lo, hi, ZK_MP(0), ZK_MP(1), ZK_MP(2), ZK_MP(3), ZK_MP(4), ZK_MP(5), ZK_MP(6), ZK_MP(7));
+#undef ZK_MP
+    }
+    template <int I>
+    static __device__ __forceinline__ void fips_low(uint64_t &lo, uint32_t &hi, uint32_t (&m)[8], const fe &a, const fe &b) {
+        col_ab<I + 1, 0, I>(lo, hi, a, b);                 // a_0 b_I + ... + a_I b_0
+        if constexpr (I > 0) col_mp<I, 0, I>(lo, hi, m);   // m_0 p_I + ... + m_{I-1} p_1
+        m[I] = (uint32_t)lo * P::inv;
+        fips::mac1_vs(lo, hi, m[I], P::p(0));              // low word of the column is now 0
+        lo = (lo >> 32) | ((uint64_t)hi << 32); hi = 0;
+    }
+    template <int I>
+    static __device__ __forceinline__ void fips_high(uint64_t &lo, uint32_t &hi, const uint32_t (&m)[8], uint32_t (&t)[8], const fe &a, const fe &b) {
+        col_ab<15 - I, I - 7, I>(lo, hi, a, b);            // a_{I-7} b_7 + ... + a_7 b_{I-7}
+        col_mp<15 - I, I - 7, I>(lo, hi, m);
+        t[I - 8] = (uint32_t)lo;
+        lo = (lo >> 32) | ((uint64_t)hi << 32); hi = 0;
+    }
+    static __device__ __forceinline__ fe mul_fips(const fe &a, const fe &b) {
+        uint64_t lo = 0; uint32_t hi = 0;
+        uint32_t m[8], t[8];
+        fips_low<0>(lo, hi, m, a, b); fips_low<1>(lo, hi, m, a, b); fips_low<2>(lo, hi, m, a, b); fips_low<3>(lo, hi, m, a, b);
+        fips_low<4>(lo, hi, m, a, b); fips_low<5>(lo, hi, m, a, b); fips_low<6>(lo, hi, m, a, b); fips_low<7>(lo, hi, m, a, b);
+        fips_high<8>(lo, hi, m, t, a, b); fips_high<9>(lo, hi, m, t, a, b); fips_high<10>(lo, hi, m, t, a, b); fips_high<11>(lo, hi, m, t, a, b);
+        fips_high<12>(lo, hi, m, t, a, b); fips_high<13>(lo, hi, m, t, a, b); fips_high<14>(lo, hi, m, t, a, b);
+        t[7] = (uint32_t)lo;                               // column 15 is empty: just the carry of column 14
+        fe r;
+#pragma unroll
+        for (int i = 0; i < 8; i++) r.l[i] = t[i];
+        return reduce_once(r);                             // a, b < p  =>  result < 2p < 2^255
+    }
+    static __device__ __forceinline__ fe mul(const fe &a, const fe &b) { return mul_fips(a, b); }
+#else
+    static ZK_HD fe mul(const fe &a, const fe &b) { return mul_cios(a, b); }
+#endif
     static ZK_HD fe sqr(const fe &a) { return mul(a, a); }
 
     static ZK_HD fe to_mont(const fe &a) { fe r2; for (int i = 0; i < 8; i++) r2.l[i] = P::r2(i); return mul(a, r2); }
