@@ -93,20 +93,14 @@ def main():
     m = r1cs.domain_size
     nB_local = pk.nB // world if shard else pk.nB
 
-    gather_buf = torch.empty((world, 640), dtype=torch.uint8, device=dev) if shard else None
+    from ethsnarks_amd.sharded import ShardedProver
+    prover = ShardedProver(ctx, dist, dev) if shard else ctx
     acc_b = []
     last_t = {}
 
     def step():
         nonlocal last_t
-        if shard:
-            part, tm = ctx.prove_partial(wm, timings=True)
-            mine = torch.from_numpy(part.view(np.uint8)).to(dev)
-            dist.all_gather_into_tensor(gather_buf.view(-1), mine)          # RCCL over xGMI: 640 B per rank
-            allp = gather_buf.cpu().numpy().view(np.uint64)
-            proof = ctx.prove_combine(allp)                                   # fixed rank order: deterministic
-        else:
-            proof, tm = ctx.prove_struct(wm, timings=True)
+        proof, tm = prover.prove_struct(wm, timings=True)     # sharded: partial sums + one RCCL all-gather of 640 B per rank
         last_t = tm
         acc_b.append(tm["acc_b"])
         return P.proof_to_json(proof, wm[1:2])

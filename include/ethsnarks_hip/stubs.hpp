@@ -1,0 +1,200 @@
+// ethsnarks_hip/stubs.hpp -- header-only C++ adapter: the reference's proving API on top of the C ABI of
+// libzkhip.so (include/zkhip.h).  It re-exports, with the reference's own names and signatures,
+//
+//   ethsnarks::load_proving_key(const char*)                      src/stubs.hpp:18,  src/stubs.cpp:36-39
+//   ethsnarks::get_domain(pb, pk, config)                         src/stubs.hpp:21,  src/stubs.cpp:61-75
+//   ethsnarks::prove(ProverContextT&, ProtoboardT&)               src/stubs.hpp:19,  src/stubs.cpp:42-47
+//   ethsnarks::stub_genkeys_from_pb(pb, pk_file, vk_file)         src/stubs.hpp:16,  src/stubs.cpp:77-87
+//   ethsnarks::stub_prove_from_pb(pb, pk_raw)                     upstream wrapper, src/pinocchio/main.cpp:10,41
+//   ethsnarks::stub_main_prove<GadgetT>(prog, argc, argv)         CLI helper shaped like stub_main_genkeys, src/stubs.hpp:36-55
+//
+// so that a gadget binary written against ethsnarks keeps its source: it includes this header instead of
+// "stubs.hpp" and links libzkhip.so instead of libsnark's prover.  The libsnark *front end* (protoboard,
+// gadgets, r1cs_constraint_system) stays what it was; only the proving key container, the prover context
+// and the prover itself are replaced.  Requires the libsnark/libff headers of the ethsnarks build
+// (they are not vendored here; the reference checkout itself ships them as empty submodules).
+//
+// The adapter flattens pb.constraint_system once per context through the accessor chain the reference's
+// own dumper uses (src/export.cpp:157-190: constraints[c]->getA().getTerms() -> {index, getCoeff()}),
+// and passes pb.values (contiguous Fr[V+1], Montgomery, ONE at index 0) by pointer.
+#pragma once
+#include <zkhip.h>
+
+#include <cstdint>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#if __has_include(<libsnark/gadgetlib1/protoboard.hpp>)
+#include <libsnark/gadgetlib1/protoboard.hpp>
+#include "ethsnarks.hpp"          // FieldT, ProtoboardT, ppT (src/ethsnarks.hpp:31-48)
+#define ETHSNARKS_HIP_HAVE_LIBSNARK 1
+#else
+#define ETHSNARKS_HIP_HAVE_LIBSNARK 0
+#endif
+
+namespace libsnark {
+// source-compatible with src/prover_config.hpp:8-35; the CPU-cache knobs are accepted and ignored
+struct Config {
+    unsigned int num_threads = 1;
+    bool smt = false;
+    std::string fft = "recursive";
+    std::vector<unsigned int> radixes;
+    bool swapAB = true;
+    unsigned int multi_exp_c = 0;
+    unsigned int multi_exp_prefetch_locality = 0;
+    unsigned int prefetch_stride = 128;
+    unsigned int multi_exp_look_ahead = 1;
+    unsigned int device = 0;               // added: HIP device ordinal
+};
+}  // namespace libsnark
+
+namespace ethsnarks {
+
+struct zk_error : std::runtime_error {
+    int code;
+    zk_error(int c) : std::runtime_error(std::string(zk_strerror(c)) + ": " + zk_last_error()), code(c) {}
+};
+inline void zk_check(int rc) { if (rc != ZK_OK) throw zk_error(rc); }
+
+// ProvingKeyT: owning handle of the nozk proving key (r1cs_gg_ppzksnark_zok_proving_key_nozk, hpp:171-274)
+class ProvingKeyT {
+public:
+    ProvingKeyT() = default;
+    explicit ProvingKeyT(zk_pk *h) : h_(h, zk_pk_free) {}
+    const zk_pk *get() const { return h_.get(); }
+private:
+    std::shared_ptr<zk_pk> h_;
+};
+
+inline ProvingKeyT load_proving_key(const char *pk_file) {
+    zk_pk *h = nullptr;
+    zk_check(zk_pk_load_raw(pk_file, ZK_CODEC_ALT_BN128, &h));     // the reference asserts on a missing file (utils.hpp:180)
+    return ProvingKeyT(h);
+}
+
+// the "domain" of the reference is an evaluation_domain object; here it is a property of the context.
+struct DomainT { uint32_t m; };
+
+// ProverContextT (hpp:279-291): borrows the key, owns device state; one per concurrent prover
+struct ProverContextT {
+    ProvingKeyT &provingKey;
+    libsnark::Config config;
+    std::shared_ptr<DomainT> domain;
+    std::shared_ptr<zk_ctx> ctx;
+    explicit ProverContextT(ProvingKeyT &pk) : provingKey(pk) {}
+};
+
+#if ETHSNARKS_HIP_HAVE_LIBSNARK
+namespace detail {
+struct Flat { std::vector<uint32_t> ptr, col; std::vector<uint64_t> coeff; };
+template <class LC> void push_row(Flat &f, const LC &lc) {
+    for (const auto &t : lc.getTerms()) {                          // src/export.cpp:157-171
+        f.col.push_back((uint32_t)t.index);
+        const FieldT c = t.getCoeff();
+        const uint64_t *limbs = reinterpret_cast<const uint64_t *>(&c);   // Fp_model<4>: 4 x u64 Montgomery limbs
+        f.coeff.insert(f.coeff.end(), limbs, limbs + 4);
+    }
+    f.ptr.push_back((uint32_t)f.col.size());
+}
+inline void ensure_context(ProverContextT &context, ProtoboardT &pb) {
+    if (context.ctx) return;
+    const auto &cs = pb.constraint_system;
+    Flat A, B, C; A.ptr = B.ptr = C.ptr = {0};
+    for (size_t c = 0; c < cs.num_constraints(); c++) {            // src/export.cpp:183-190
+        push_row(A, cs.constraints[c]->getA()); push_row(B, cs.constraints[c]->getB()); push_row(C, cs.constraints[c]->getC());
+    }
+    zk_csr a{(uint32_t)cs.num_constraints(), A.ptr.data(), A.col.data(), A.coeff.data()};
+    zk_csr b{(uint32_t)cs.num_constraints(), B.ptr.data(), B.col.data(), B.coeff.data()};
+    zk_csr c{(uint32_t)cs.num_constraints(), C.ptr.data(), C.col.data(), C.coeff.data()};
+    zk_config cfg{context.config.multi_exp_c, context.config.device, 0, 1};
+    zk_ctx *h = nullptr;
+    zk_check(zk_ctx_create(context.provingKey.get(), &a, &b, &c, (uint32_t)cs.num_constraints(), (uint32_t)cs.num_inputs(),
+                           (uint32_t)cs.num_variables(), &cfg, &h));
+    context.ctx.reset(h, zk_ctx_destroy);
+}
+}  // namespace detail
+
+// get_domain (src/stubs.cpp:61-75): same size rule; building the context uploads key + CSR and the twiddles
+inline std::shared_ptr<DomainT> get_domain(ProtoboardT &pb, const ProvingKeyT &, const libsnark::Config &) {
+    const auto &cs = pb.constraint_system;
+    return std::make_shared<DomainT>(DomainT{zk_domain_size((uint32_t)cs.num_constraints(), (uint32_t)cs.num_inputs())});
+}
+
+// prove (src/stubs.cpp:42-47): proof JSON of src/export.cpp:99-121
+inline std::string prove(ProverContextT &context, ProtoboardT &pb) {
+    detail::ensure_context(context, pb);
+    const uint64_t *w = reinterpret_cast<const uint64_t *>(pb.values.data());     // ONE at index 0 (tcc:492-493)
+    zk_proof proof;
+    zk_check(zk_prove(context.ctx.get(), w, /*canonical=*/0, &proof));
+    const uint32_t nIn = (uint32_t)pb.constraint_system.num_inputs();
+    size_t len = 0;
+    zk_proof_to_json(&proof, w + 4, nIn, 0, nullptr, 0, &len);
+    std::string out(len + 1, '\0');
+    zk_check(zk_proof_to_json(&proof, w + 4, nIn, 0, &out[0], out.size(), &len));
+    out.resize(len);
+    return out;
+}
+
+inline std::string stub_prove_from_pb(ProtoboardT &pb, const char *pk_raw) {        // src/pinocchio/main.cpp:41
+    ProvingKeyT pk = load_proving_key(pk_raw);
+    ProverContextT context(pk);
+    context.config = libsnark::Config();
+    context.domain = get_domain(pb, pk, context.config);
+    return prove(context, pb);
+}
+
+inline int stub_genkeys_from_pb(ProtoboardT &pb, const char *pk_file, const char *vk_file) {   // src/stubs.cpp:77-87
+    const auto &cs = pb.constraint_system;
+    detail::Flat A, B, C; A.ptr = B.ptr = C.ptr = {0};
+    for (size_t c = 0; c < cs.num_constraints(); c++) {
+        detail::push_row(A, cs.constraints[c]->getA()); detail::push_row(B, cs.constraints[c]->getB()); detail::push_row(C, cs.constraints[c]->getC());
+    }
+    zk_csr a{(uint32_t)cs.num_constraints(), A.ptr.data(), A.col.data(), A.coeff.data()};
+    zk_csr b{(uint32_t)cs.num_constraints(), B.ptr.data(), B.col.data(), B.coeff.data()};
+    zk_csr c{(uint32_t)cs.num_constraints(), C.ptr.data(), C.col.data(), C.coeff.data()};
+    uint64_t toxic[20];
+    for (int i = 0; i < 5; i++) {                                   // t, alpha, beta, gamma, delta (tcc:283-287)
+        const auto v = FieldT::random_element().as_bigint();
+        std::memcpy(toxic + 4 * i, v.data, 32);
+    }
+    zk_pk *pk = nullptr; zk_vk *vk = nullptr;
+    if (zk_keygen(&a, &b, &c, (uint32_t)cs.num_constraints(), (uint32_t)cs.num_inputs(), (uint32_t)cs.num_variables(), toxic, 0, &pk, &vk) != ZK_OK) return 1;
+    size_t len = 0;
+    zk_vk_to_json(vk, nullptr, 0, &len);
+    std::string js(len + 1, '\0');
+    int rc = zk_vk_to_json(vk, &js[0], js.size(), &len);
+    if (rc == ZK_OK) { std::ofstream fh(vk_file, std::ios::binary); fh.write(js.data(), (std::streamsize)len); rc = fh ? ZK_OK : ZK_ERR_IO; }
+    if (rc == ZK_OK) rc = zk_pk_save_raw(pk, pk_file, ZK_CODEC_ALT_BN128);
+    zk_pk_free(pk); zk_vk_free(vk);
+    return rc == ZK_OK ? 0 : 1;
+}
+
+// stub_main_prove: argv helper shaped like stub_main_genkeys (src/stubs.hpp:36-55)
+template <class GadgetT>
+int stub_main_prove(const char *prog_name, int argc, char **argv) {
+    if (argc < 3) {
+        std::cerr << "Usage: " << prog_name << " " << argv[0] << " <pk-input.raw> <proof-output.json>" << std::endl;
+        return 1;
+    }
+    ppT::init_public_params();
+    ProtoboardT pb;
+    GadgetT mod(pb, "module");
+    mod.generate_r1cs_constraints();
+    mod.generate_r1cs_witness();
+    try {
+        std::ofstream fh(argv[2], std::ios::binary);
+        fh << stub_prove_from_pb(pb, argv[1]);
+        return fh ? 0 : 1;
+    } catch (const std::exception &e) {
+        std::cerr << "Error: failed to prove: " << e.what() << std::endl;
+        return 1;
+    }
+}
+#endif  // ETHSNARKS_HIP_HAVE_LIBSNARK
+
+}  // namespace ethsnarks
