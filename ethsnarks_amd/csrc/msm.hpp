@@ -14,9 +14,10 @@
 // 16x fewer buckets to reduce, ~n*W/2^(c-1) entries per bucket so fixed-length segments are full.
 //
 // Per proof (integer VALU work; random 64/128-B gathers from the table):
-//   1 k_msm_digits      scalar -> canonical -> signed c-bit digits; bucket histogram
-//   2 k_msm_scan_*      exclusive scans: entries per bucket, fixed-length *segments* per bucket
-//   3 k_msm_scatter     counting-sort scatter of (table index, sign) by bucket
+//   1 k_sort_count / k_sort_colscan / k_sort_binscan / k_sort_partition   scalar -> signed c-bit digits ->
+//                       entries partitioned into <= 256 coarse bucket bins (LDS ranking, no global atomics)
+//   2 k_sort_fine       one workgroup per coarse bin: LDS histogram + in-L2 scatter by bucket
+//   3 k_msm_scan_*      exclusive scan: fixed-length *segments* per bucket
 //   4 k_msm_accumulate  one thread per segment: XYZZ mixed additions            <- dominant kernel
 //   5 k_msm_bucket_finalize / k_msm_heavy   segment sums -> bucket sums
 //   6 k_msm_group_reduce   sum_b (b+1) * B_b over groups of buckets (running sums + small offset multiple)
@@ -42,6 +43,22 @@ constexpr uint32_t MSM_HEAVY_GRID = 2;    // the emulator spawns a real thread p
 constexpr uint32_t MSM_HEAVY_GRID = 256;
 #endif
 
+// shapes of the two-pass bucket sort (msm_impl.hpp)
+constexpr uint32_t SORT_THREADS = 256;
+constexpr uint32_t SORT_MAX_CB = 256;          // coarse bins
+constexpr uint32_t SORT_MAX_FB = 4096;         // fine buckets per coarse bin held in LDS (c <= 20)
+
+struct SortShape {
+    uint32_t cb, fb, fine_bits, groups, per_group;   // groups = workgroups of pass 1, per_group = scalars each
+    void set(uint32_t n, uint32_t nb) {
+        cb = nb < SORT_MAX_CB ? nb : SORT_MAX_CB;
+        fb = nb / cb;
+        fine_bits = 0; while ((1u << fine_bits) < fb) fine_bits++;
+        per_group = 1024;                                   // 1024 scalars x W windows of LDS-ranked entries per workgroup
+        groups = (n + per_group - 1) / per_group; if (!groups) groups = 1;
+    }
+};
+
 struct MsmShape {
     uint32_t n = 0, c = 0, W = 0, nb = 0, seg = MSM_SEG_MIN;
     // largest window with >= 32 entries per bucket on average (n * W entries over 2^(c-1) buckets)
@@ -65,9 +82,12 @@ struct MsmShape {
 template <class C>
 struct MsmWork {
     MsmShape sh;
+    SortShape ss;
     typename C::Affine *table = nullptr;        // [W][table_n] window multiples of the bases, resident for the context's life
     uint32_t table_n = 0;
-    uint32_t *keys = nullptr, *hist = nullptr, *off = nullptr, *segoff = nullptr, *cursor = nullptr, *sorted = nullptr;
+    uint2 *pairs = nullptr;                     // pass-1 output of the bucket sort: (payload, bucket)
+    uint32_t *counts = nullptr, *bin_total = nullptr, *bin_base = nullptr;
+    uint32_t *hist = nullptr, *off = nullptr, *segoff = nullptr, *cursor = nullptr, *sorted = nullptr;
     uint32_t *heavy_list = nullptr, *heavy_count = nullptr, *tile_a = nullptr, *tile_b = nullptr;
     typename C::XYZZ *segsum = nullptr, *bucket = nullptr, *partial_a = nullptr, *partial_b = nullptr;
     typename C::XYZZ *host_result = nullptr;    // pinned, 1 entry

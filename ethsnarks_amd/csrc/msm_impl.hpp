@@ -23,30 +23,151 @@ k_msm_precompute(const typename C::Affine *__restrict__ bases, uint32_t n, uint3
     }
 }
 
-// scalar i of this MSM = scalars[gather ? gather[i] : i]; Montgomery unless canonical != 0
-template <class C>
-__global__ void
-k_msm_digits(const fe *__restrict__ scalars, const uint32_t *__restrict__ gather, uint32_t n,
-             int canonical, uint32_t c, uint32_t W, uint32_t *__restrict__ keys, uint32_t *__restrict__ hist) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    fe s = scalars[gather ? gather[i] : i];
-    if (!canonical) s = Fr::from_mont(s);
+// ---- bucket sort of the n*W digit entries, without global atomics ---------------------------------
+// Pass 1 partitions the entries into CB <= 256 *coarse* bins (high bits of the bucket id): every workgroup
+// owns a contiguous run of scalars, counts its entries per coarse bin in LDS (k_sort_count), a column scan
+// turns the [bin][workgroup] count matrix into write positions (k_sort_colscan / k_sort_binscan), and the
+// workgroup re-derives its digits and writes (bucket, payload) pairs at LDS-ranked positions
+// (k_sort_partition): runs of ~64 consecutive pairs per bin per workgroup.  Pass 2 gives every coarse bin
+// to one workgroup (k_sort_fine): LDS histogram of its <= 2^15/CB fine buckets, local scan, and an in-L2
+// scatter of the payloads.  It also emits the bucket histogram and offsets.  payload = table index | sign.
+// signed c-bit digit of window w (carry in/out); returns magnitude (0 = no entry) and sign
+static ZK_D uint32_t msm_digit(const fe &s, uint32_t w, uint32_t c, uint32_t &carry, uint32_t &neg) {
     const uint32_t nb = 1u << (c - 1), full = 1u << c;
-    uint32_t carry = 0;
-    for (uint32_t w = 0; w < W; w++) {
-        uint32_t bit = w * c, limb = bit >> 5, off = bit & 31;
-        uint32_t lo = 0, hi = 0;                                // static selects: keeps the scalar in VGPRs
+    uint32_t bit = w * c, limb = bit >> 5, off = bit & 31;
+    uint32_t lo = 0, hi = 0;                                    // static selects: keeps the scalar in VGPRs
 #pragma unroll
-        for (uint32_t k = 0; k < 8; k++) { if (k == limb) lo = s.l[k]; if (k == limb + 1) hi = s.l[k]; }
-        uint64_t v = lo | ((uint64_t)hi << 32);
-        uint32_t d = ((uint32_t)(v >> off) & (full - 1)) + carry;
-        uint32_t neg = 0;
-        carry = 0;
-        if (d > nb) { d = full - d; neg = 1; carry = 1; }     // digit in [-2^(c-1)+1, 2^(c-1)]
-        uint32_t key = MSM_KEY_NONE;
-        if (d) { key = (d - 1) | (neg << 31); atomicAdd(&hist[d - 1], 1u); }
-        keys[(size_t)w * n + i] = key;
+    for (uint32_t k = 0; k < 8; k++) { if (k == limb) lo = s.l[k]; if (k == limb + 1) hi = s.l[k]; }
+    uint64_t v = lo | ((uint64_t)hi << 32);
+    uint32_t d = ((uint32_t)(v >> off) & (full - 1)) + carry;
+    neg = 0; carry = 0;
+    if (d > nb) { d = full - d; neg = 1; carry = 1; }         // digit in [-2^(c-1)+1, 2^(c-1)]
+    return d;
+}
+static ZK_D fe msm_load_scalar(const fe *__restrict__ scalars, const uint32_t *__restrict__ gather, uint32_t i, int canonical) {
+    fe s = scalars[gather ? gather[i] : i];                    // scalar i of this MSM; Montgomery unless canonical
+    return canonical ? s : Fr::from_mont(s);
+}
+
+// counts[bin * groups + group] = entries of this workgroup's scalars that fall into coarse bin `bin`
+template <class C>
+__global__ void __launch_bounds__(SORT_THREADS)
+k_sort_count(const fe *__restrict__ scalars, const uint32_t *__restrict__ gather, uint32_t n, int canonical,
+             uint32_t c, uint32_t W, SortShape ss, uint32_t *__restrict__ counts) {
+    __shared__ uint32_t cnt[SORT_MAX_CB];
+    for (uint32_t k = threadIdx.x; k < ss.cb; k += blockDim.x) cnt[k] = 0;
+    __syncthreads();
+    const uint32_t i0 = blockIdx.x * ss.per_group, i1 = (i0 + ss.per_group < n) ? i0 + ss.per_group : n;
+    for (uint32_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+        const fe s = msm_load_scalar(scalars, gather, i, canonical);
+        uint32_t carry = 0, neg;
+        for (uint32_t w = 0; w < W; w++) {
+            uint32_t d = msm_digit(s, w, c, carry, neg);
+            if (d) atomicAdd(&cnt[(d - 1) >> ss.fine_bits], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < ss.cb; k += blockDim.x) counts[(size_t)k * ss.groups + blockIdx.x] = cnt[k];
+}
+
+// one workgroup per coarse bin: exclusive scan of its row counts[bin][0..groups) in place; bin total out
+template <class C>
+__global__ void __launch_bounds__(SORT_THREADS)
+k_sort_colscan(uint32_t *__restrict__ counts, uint32_t groups, uint32_t *__restrict__ bin_total) {
+    __shared__ uint32_t sh[SORT_THREADS];
+    uint32_t *row = counts + (size_t)blockIdx.x * groups;
+    const uint32_t t = threadIdx.x, per = (groups + SORT_THREADS - 1) / SORT_THREADS;
+    const uint32_t g0 = t * per, g1 = (g0 + per < groups) ? g0 + per : groups;
+    uint32_t sum = 0;
+    for (uint32_t g = g0; g < g1; g++) sum += row[g];
+    sh[t] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < SORT_THREADS; d <<= 1) {
+        uint32_t v = (t >= d) ? sh[t - d] : 0;
+        __syncthreads();
+        sh[t] += v;
+        __syncthreads();
+    }
+    uint32_t e = sh[t] - sum;
+    for (uint32_t g = g0; g < g1; g++) { uint32_t v = row[g]; row[g] = e; e += v; }
+    if (t == SORT_THREADS - 1) bin_total[blockIdx.x] = sh[t];
+}
+
+// single workgroup: bin_base[k] = sum of bin_total[0..k), bin_base[cb] = total entries
+template <class C>
+__global__ void __launch_bounds__(SORT_THREADS)
+k_sort_binscan(const uint32_t *__restrict__ bin_total, uint32_t cb, uint32_t *__restrict__ bin_base) {
+    __shared__ uint32_t sh[SORT_THREADS];
+    const uint32_t t = threadIdx.x, v0 = t < cb ? bin_total[t] : 0;
+    sh[t] = v0;
+    __syncthreads();
+    for (uint32_t d = 1; d < SORT_THREADS; d <<= 1) {
+        uint32_t v = (t >= d) ? sh[t - d] : 0;
+        __syncthreads();
+        sh[t] += v;
+        __syncthreads();
+    }
+    if (t < cb) bin_base[t] = sh[t] - v0;
+    if (t == SORT_THREADS - 1) bin_base[cb] = sh[t];
+}
+
+// pass 1 scatter: (bucket, payload) pairs into the coarse-bin regions, LDS-ranked
+template <class C>
+__global__ void __launch_bounds__(SORT_THREADS)
+k_sort_partition(const fe *__restrict__ scalars, const uint32_t *__restrict__ gather, uint32_t n, int canonical,
+                 uint32_t c, uint32_t W, SortShape ss, const uint32_t *__restrict__ counts,
+                 const uint32_t *__restrict__ bin_base, uint2 *__restrict__ pairs) {
+    __shared__ uint32_t pos[SORT_MAX_CB];
+    for (uint32_t k = threadIdx.x; k < ss.cb; k += blockDim.x) pos[k] = bin_base[k] + counts[(size_t)k * ss.groups + blockIdx.x];
+    __syncthreads();
+    const uint32_t i0 = blockIdx.x * ss.per_group, i1 = (i0 + ss.per_group < n) ? i0 + ss.per_group : n;
+    for (uint32_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+        const fe s = msm_load_scalar(scalars, gather, i, canonical);
+        uint32_t carry = 0, neg;
+        for (uint32_t w = 0; w < W; w++) {
+            uint32_t d = msm_digit(s, w, c, carry, neg);
+            if (!d) continue;
+            uint32_t p = atomicAdd(&pos[(d - 1) >> ss.fine_bits], 1u);
+            uint2 e; e.x = (w * n + i) | (neg << 31); e.y = d - 1;      // table index of 2^(cw) P_i, sign; bucket
+            pairs[p] = e;
+        }
+    }
+}
+
+// pass 2: one workgroup per coarse bin sorts its region by fine bucket; emits hist[], off[] and sorted[]
+template <class C>
+__global__ void __launch_bounds__(SORT_THREADS)
+k_sort_fine(const uint2 *__restrict__ pairs, const uint32_t *__restrict__ bin_base, SortShape ss,
+            uint32_t *__restrict__ hist, uint32_t *__restrict__ off, uint32_t *__restrict__ sorted) {
+    __shared__ uint32_t cnt[SORT_MAX_FB], cur[SORT_MAX_FB], sh[SORT_THREADS];
+    const uint32_t bin = blockIdx.x, r0 = bin_base[bin], r1 = bin_base[bin + 1], t = threadIdx.x;
+    const uint32_t fmask = ss.fb - 1;
+    for (uint32_t k = t; k < ss.fb; k += blockDim.x) cnt[k] = 0;
+    __syncthreads();
+    for (uint32_t e = r0 + t; e < r1; e += blockDim.x) atomicAdd(&cnt[pairs[e].y & fmask], 1u);
+    __syncthreads();
+    // exclusive scan of cnt[0..fb): thread-serial runs + Hillis-Steele over the run sums
+    const uint32_t per = (ss.fb + SORT_THREADS - 1) / SORT_THREADS, k0 = t * per, k1 = (k0 + per < ss.fb) ? k0 + per : ss.fb;
+    uint32_t sum = 0;
+    for (uint32_t k = k0; k < k1; k++) sum += cnt[k];
+    sh[t] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < SORT_THREADS; d <<= 1) {
+        uint32_t v = (t >= d) ? sh[t - d] : 0;
+        __syncthreads();
+        sh[t] += v;
+        __syncthreads();
+    }
+    uint32_t ex = sh[t] - sum;
+    for (uint32_t k = k0; k < k1; k++) {
+        const uint32_t b = bin * ss.fb + k;
+        hist[b] = cnt[k]; off[b] = r0 + ex; cur[k] = r0 + ex;
+        ex += cnt[k];
+    }
+    __syncthreads();
+    for (uint32_t e = r0 + t; e < r1; e += blockDim.x) {
+        const uint2 pr = pairs[e];
+        sorted[atomicAdd(&cur[pr.y & fmask], 1u)] = pr.x;
     }
 }
 
@@ -118,21 +239,6 @@ k_msm_scan_add(uint32_t nbk, uint32_t ntiles, const uint32_t *__restrict__ tile_
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < nbk) { const uint32_t tl = b / SCAN_TILE; off[b] += tile_a[tl]; segoff[b] += tile_b[tl]; cursor[b] = 0; }
     if (b == nbk) { off[nbk] = tile_a[ntiles]; segoff[nbk] = tile_b[ntiles]; }
-}
-
-template <class C>
-__global__ void
-k_msm_scatter(const uint32_t *__restrict__ keys, uint32_t n, uint32_t W, const uint32_t *__restrict__ off,
-              uint32_t *__restrict__ cursor, uint32_t *__restrict__ sorted) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    for (uint32_t w = 0; w < W; w++) {
-        uint32_t key = keys[(size_t)w * n + i];
-        if (key == MSM_KEY_NONE) continue;
-        uint32_t b = key & 0x7fffffffu;
-        uint32_t pos = off[b] + atomicAdd(&cursor[b], 1u);
-        sorted[pos] = (w * n + i) | (key & 0x80000000u);        // table index of 2^(cw) P_i, sign of the digit
-    }
 }
 
 // thread per segment; the segment -> bucket map is a binary search in segoff[] (nb + 1 entries)
@@ -233,7 +339,11 @@ int MsmWork<C>::alloc(uint32_t n, uint32_t c) {
     sh.set(n ? n : 1, c);
     const uint32_t K = sh.nb < MSM_GROUP ? sh.nb : MSM_GROUP, groups = sh.nb / K;
     ZK_HIP(hipMalloc(&table, sizeof(typename C::Affine) * sh.max_entries()));
-    ZK_HIP(hipMalloc(&keys, sizeof(uint32_t) * sh.max_entries()));
+    ss.set(sh.n, sh.nb);
+    ZK_HIP(hipMalloc(&pairs, sizeof(uint2) * sh.max_entries()));
+    ZK_HIP(hipMalloc(&counts, sizeof(uint32_t) * ((size_t)ss.cb * ss.groups + 1)));
+    ZK_HIP(hipMalloc(&bin_total, sizeof(uint32_t) * (SORT_MAX_CB + 1)));
+    ZK_HIP(hipMalloc(&bin_base, sizeof(uint32_t) * (SORT_MAX_CB + 1)));
     ZK_HIP(hipMalloc(&sorted, sizeof(uint32_t) * sh.max_entries()));
     ZK_HIP(hipMalloc(&hist, sizeof(uint32_t) * (sh.nb + 1)));
     ZK_HIP(hipMalloc(&off, sizeof(uint32_t) * (sh.nb + 1)));
@@ -254,7 +364,7 @@ int MsmWork<C>::alloc(uint32_t n, uint32_t c) {
 
 template <class C>
 void MsmWork<C>::release() {
-    void *dev[] = {table, keys, hist, off, segoff, cursor, sorted, heavy_list, heavy_count, tile_a, tile_b, segsum, bucket, partial_a, partial_b};
+    void *dev[] = {table, pairs, counts, bin_total, bin_base, hist, off, segoff, cursor, sorted, heavy_list, heavy_count, tile_a, tile_b, segsum, bucket, partial_a, partial_b};
     for (void *p : dev) if (p) hipFree(p);
     if (host_result) hipHostFree(host_result);
     if (ev_acc0) hipEventDestroy(ev_acc0);
@@ -276,16 +386,20 @@ int MsmWork<C>::enqueue(const fe *scalars, const uint32_t *gather, uint32_t n, i
     if (n != table_n) return ZK_ERR_ARG;                        // the table stride is the precompute-time n
     const uint32_t c = sh.c, W = sh.W, nb = sh.nb, seg = sh.seg;
     const uint32_t K = nb < MSM_GROUP ? nb : MSM_GROUP, groups = nb / K;
-    ZK_HIP(hipMemsetAsync(hist, 0, sizeof(uint32_t) * (nb + 1), st));
     ZK_HIP(hipMemsetAsync(heavy_count, 0, sizeof(uint32_t), st));
-    if (n) ZK_LAUNCH(k_msm_digits<C>, zk_div_up(n, 256), 256, st, scalars, gather, n, canonical, c, W, keys, hist);
-    {
+    SortShape sq = ss; sq.set(n ? n : 1, nb);                   // same bins; workgroups sized for this call's n
+    ZK_LAUNCH_SYNC(k_sort_count<C>, sq.groups, SORT_THREADS, st, scalars, gather, n, canonical, c, W, sq, counts);
+    ZK_LAUNCH_SYNC(k_sort_colscan<C>, sq.cb, SORT_THREADS, st, counts, sq.groups, bin_total);
+    ZK_LAUNCH_SYNC(k_sort_binscan<C>, 1, SORT_THREADS, st, (const uint32_t *)bin_total, sq.cb, bin_base);
+    ZK_LAUNCH_SYNC(k_sort_partition<C>, sq.groups, SORT_THREADS, st, scalars, gather, n, canonical, c, W, sq,
+                   (const uint32_t *)counts, (const uint32_t *)bin_base, pairs);
+    ZK_LAUNCH_SYNC(k_sort_fine<C>, sq.cb, SORT_THREADS, st, (const uint2 *)pairs, (const uint32_t *)bin_base, sq, hist, off, sorted);
+    {   // segments per bucket (and the same off[] again) from the histogram
         const uint32_t ntiles = zk_div_up(nb, SCAN_TILE);
         ZK_LAUNCH_SYNC(k_msm_scan_local<C>, ntiles, SCAN_THREADS, st, (const uint32_t *)hist, nb, seg, off, segoff, tile_a, tile_b);
         ZK_LAUNCH_SYNC(k_msm_scan_totals<C>, 1, 1024, st, tile_a, tile_b, ntiles);
         ZK_LAUNCH(k_msm_scan_add<C>, zk_div_up(nb + 1, 256), 256, st, nb, ntiles, (const uint32_t *)tile_a, (const uint32_t *)tile_b, off, segoff, cursor);
     }
-    if (n) ZK_LAUNCH(k_msm_scatter<C>, zk_div_up(n, 256), 256, st, (const uint32_t *)keys, n, W, (const uint32_t *)off, cursor, sorted);
     // segment count is only known on the device: launch for the upper bound, threads past segoff[nb] exit.
     const uint64_t max_seg = (uint64_t)n * W / seg + nb + 1;
     ZK_HIP(hipEventRecord(ev_acc0, st));

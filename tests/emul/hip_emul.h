@@ -4,19 +4,18 @@
 // ethsnarks_amd/csrc (indexing, scans, bucket bookkeeping, barrier placement) can be exercised by
 // `pytest -m "not gpu"` in a container that has no GPU.  The same kernel sources are compiled with
 // g++ -DZK_EMUL into tests/emul/libzkhip_emul.so; a "launch" runs the blocks one after another, the
-// threads of a block either sequentially (kernels without block barriers) or as real threads with a
-// barrier (kernels that call __syncthreads()).  The product (libzkhip.so) never sees this file, the
+// threads of a block either sequentially (kernels without block barriers) or as cooperative fibers that
+// yield at __syncthreads() (kernels with barriers).  The product (libzkhip.so) never sees this file, the
 // Python package never loads the emulation library, and nothing here is ever timed or shipped.
 #pragma once
 #include <atomic>
-#include <condition_variable>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
-#include <mutex>
-#include <thread>
+#include <ucontext.h>
+#include <time.h>
 #include <vector>
 
 #define __global__
@@ -31,43 +30,63 @@ struct dim3 {
     dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
 inline thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
+struct uint2 { unsigned x, y; };
 
 namespace zk_emul {
-struct Barrier {
-    std::mutex m; std::condition_variable cv; unsigned n = 0, waiting = 0, gen = 0;
-    void wait() {
-        std::unique_lock<std::mutex> lk(m);
-        unsigned g = gen;
-        if (++waiting == n) { waiting = 0; gen++; cv.notify_all(); }
-        else cv.wait(lk, [&] { return gen != g; });
-    }
-};
-inline Barrier *g_barrier = nullptr;
+// Workgroups that use __syncthreads() run as cooperative fibers (ucontext) inside the calling OS thread:
+// a fiber runs until its next barrier, then the scheduler resumes the next one; one sweep over all fibers
+// completes the barrier.  (Real threads cost a context switch per thread per barrier: ~100x slower.)
+struct Fiber { ucontext_t ctx; bool done; };
+inline ucontext_t g_sched;
+inline Fiber *g_cur = nullptr;
+inline std::function<void()> *g_body = nullptr;
+inline std::vector<Fiber> g_fibers;
+inline std::vector<char> g_stacks;
+constexpr size_t FIBER_STACK = 256 * 1024;
+inline void trampoline() { (*g_body)(); g_cur->done = true; }
 
 template <class Body>
 void launch(bool needs_sync, dim3 grid, dim3 block, Body body) {
-    for (unsigned bx = 0; bx < grid.x; bx++) {
-        if (!needs_sync) {
+    if (!needs_sync) {
+        for (unsigned bx = 0; bx < grid.x; bx++)
             for (unsigned tx = 0; tx < block.x; tx++) {
                 threadIdx = dim3(tx); blockIdx = dim3(bx); blockDim = block; gridDim = grid;
                 body();
             }
-        } else {
-            Barrier bar; bar.n = block.x; g_barrier = &bar;
-            std::vector<std::thread> th;
-            for (unsigned tx = 0; tx < block.x; tx++)
-                th.emplace_back([&, tx] {
-                    threadIdx = dim3(tx); blockIdx = dim3(bx); blockDim = block; gridDim = grid;
-                    body();
-                });
-            for (auto &t : th) t.join();
-            g_barrier = nullptr;
+        return;
+    }
+    std::function<void()> fn = body;
+    g_body = &fn;
+    if (g_fibers.size() < block.x) g_fibers.resize(block.x);
+    if (g_stacks.size() < (size_t)block.x * FIBER_STACK) g_stacks.resize((size_t)block.x * FIBER_STACK);
+    for (unsigned bx = 0; bx < grid.x; bx++) {
+        for (unsigned tx = 0; tx < block.x; tx++) {
+            Fiber &f = g_fibers[tx];
+            getcontext(&f.ctx);
+            f.ctx.uc_stack.ss_sp = g_stacks.data() + (size_t)tx * FIBER_STACK;
+            f.ctx.uc_stack.ss_size = FIBER_STACK;
+            f.ctx.uc_link = &g_sched;
+            f.done = false;
+            makecontext(&f.ctx, (void (*)())trampoline, 0);
+        }
+        bool any = true;
+        while (any) {
+            any = false;
+            for (unsigned tx = 0; tx < block.x; tx++) {
+                Fiber &f = g_fibers[tx];
+                if (f.done) continue;
+                threadIdx = dim3(tx); blockIdx = dim3(bx); blockDim = block; gridDim = grid;
+                g_cur = &f;
+                swapcontext(&g_sched, &f.ctx);
+                if (!f.done) any = true;
+            }
         }
     }
+    g_cur = nullptr; g_body = nullptr;
 }
 }  // namespace zk_emul
 
-inline void __syncthreads() { if (zk_emul::g_barrier) zk_emul::g_barrier->wait(); }
+inline void __syncthreads() { if (zk_emul::g_cur) swapcontext(&zk_emul::g_cur->ctx, &zk_emul::g_sched); }
 inline unsigned atomicAdd(unsigned *p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 inline unsigned atomicMax(unsigned *p, unsigned v) {
