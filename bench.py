@@ -9,8 +9,11 @@ on a real proving key produced by this library's GPU key generator (seeded toxic
 constraint system resident in HBM, witness handed over as a host buffer (its 33.5 MB upload is inside the
 timed region).  N > 1 (launched by torch.distributed.run, one rank per GPU): the MSM base ranges of
 the key are sharded over the ranks, every rank proves its shard, the 640-byte partial results are
-exchanged with one RCCL all-gather and folded in rank order ("strong" scaling: one proof at a time
-across all GPUs).  --mode replicas runs N independent provers instead ("weak").
+exchanged with one RCCL all-gather and folded in rank order ("strong" scaling: the GPUs share each
+proof).  --mode replicas runs N independent provers instead ("weak").  --inflight K (default 2) keeps K
+prover contexts per GPU busy through the asynchronous zk_prove_submit / zk_prove_collect pair, so the next
+proof's witness upload and sort overlap the bucket-reduction tails of the current one; every step still
+completes a full proof, and --inflight 1 gives the one-proof-at-a-time latency figure.
 
 Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (k_msm_accumulate over G2,
 the B-query); `cpu_baseline` is the CPU oracle (oracle/, a restatement of the reference prover --
@@ -54,6 +57,9 @@ def main():
     ap.add_argument("--logm", type=int, default=20, help="domain size 2^logm (nC = 2^logm - 2)")
     ap.add_argument("--mode", choices=["shard", "replicas"], default="shard")
     ap.add_argument("--multi-exp-c", type=int, default=0)
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="prover contexts kept in flight per GPU (1 = one synchronous proof at a time; 2 overlaps the "
+                         "next proof's upload/sort with the current proof's bucket-reduction tails)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-logm", type=int, default=0, help="size of the CPU-baseline sample (default: same as --logm)")
     args = ap.parse_args()
@@ -88,22 +94,40 @@ def main():
     pk, vk = P.keygen(r1cs, seed=R.SEED_DEFAULT, device=local_rank)   # same seeded key on every rank
     t_keygen = time.time() - t0
     shard = world > 1 and args.mode == "shard"
-    ctx = P.ProverContext(pk, r1cs, multi_exp_c=args.multi_exp_c, device=local_rank,
-                          shard_rank=rank if shard else 0, shard_count=world if shard else 1)
+    ctxs = [P.ProverContext(pk, r1cs, multi_exp_c=args.multi_exp_c, device=local_rank,
+                            shard_rank=rank if shard else 0, shard_count=world if shard else 1)
+            for _ in range(max(1, args.inflight))]
     m = r1cs.domain_size
     nB_local = pk.nB // world if shard else pk.nB
-
-    from ethsnarks_amd.sharded import ShardedProver
-    prover = ShardedProver(ctx, dist, dev) if shard else ctx
+    gather_buf = torch.empty((world, 640), dtype=torch.uint8, device=dev) if shard else None
     acc_b = []
     last_t = {}
+    pending = []
 
-    def step():
+    def finish(slot):
+        """collect slot's proof; sharded: one RCCL all-gather of the 640-byte partials, folded in rank order"""
         nonlocal last_t
-        proof, tm = prover.prove_struct(wm, timings=True)     # sharded: partial sums + one RCCL all-gather of 640 B per rank
+        part, tm = ctxs[slot].collect()
+        if shard:
+            mine = torch.from_numpy(part.view(np.uint8).copy()).to(dev)
+            dist.all_gather_into_tensor(gather_buf.view(-1), mine)
+            part = gather_buf.cpu().numpy().reshape(-1).view(np.uint64)
+        proof = ctxs[slot].prove_combine(part)
         last_t = tm
         acc_b.append(tm["acc_b"])
         return P.proof_to_json(proof, wm[1:2])
+
+    def run(nsteps):
+        js = None
+        for i in range(nsteps):
+            if len(pending) == len(ctxs):
+                js = finish(pending.pop(0))
+            slot = i % len(ctxs)
+            ctxs[slot].submit(wm)
+            pending.append(slot)
+        while pending:
+            js = finish(pending.pop(0))
+        return js
 
     def sync():
         torch.cuda.synchronize()
@@ -111,14 +135,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    js = None
-    for _ in range(args.warmup):
-        js = step()
+    js = run(args.warmup) if args.warmup else None
     acc_b.clear()
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        js = step()
+    js = run(args.steps)
     sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -145,7 +166,7 @@ def main():
             "constraints_per_sec": round(value * nC, 1),
             "config": {"workload": "synthetic chain R1CS (SURVEY 8d), nC=2^%d-2=%d, nIn=1, V=%d, domain m=2^%d; real seeded Groth16 key" % (logm, nC, r1cs.V, logm),
                        "parallelism": ("msm-shard%d+allgather640B" % world) if shard else ("replicas%d" % world if world > 1 else "1gpu"),
-                       "multi_exp_c": args.multi_exp_c or P_pick_c(nB_local), "witness": "host buffer, H2D inside the timed region"},
+                       "multi_exp_c": args.multi_exp_c or P_pick_c(nB_local), "witness": "host buffer, H2D inside the timed region", "inflight": len(ctxs)},
             "roofline": {"kernel": "k_msm_accumulate<G2> (B-query bucket accumulation)", "bound": "hbm",
                          "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": None,
@@ -170,10 +191,11 @@ def main():
 
 
 def P_pick_c(n):
-    c = 2
-    while c < 16 and (1 << (c + 4)) <= n:
-        c += 1
-    return c
+    """mirror of MsmShape::pick_c (ethsnarks_amd/csrc/msm.hpp)"""
+    for c in range(17, 2, -1):
+        if n * (254 // c + 1) >= (32 << (c - 1)):
+            return c
+    return 2
 
 
 def proof_bytes(r1cs, pk, m):

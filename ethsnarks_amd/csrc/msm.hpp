@@ -28,6 +28,7 @@
 #pragma once
 #include "bn254.hpp"
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace zk {
 
@@ -63,7 +64,7 @@ struct MsmShape {
     uint32_t n = 0, c = 0, W = 0, nb = 0, seg = MSM_SEG_MIN;
     // largest window with >= 32 entries per bucket on average (n * W entries over 2^(c-1) buckets)
     static uint32_t pick_c(uint32_t n) {
-        for (uint32_t c = 16; c > 2; c--)
+        for (uint32_t c = 17; c > 2; c--)      // 17: measured optimum at n = 2^20 (W = 15 windows, 2^16 buckets)
             if ((uint64_t)n * (254 / c + 1) >= ((uint64_t)MSM_SEG_MIN << (c - 1))) return c;
         return 2;
     }
@@ -73,7 +74,9 @@ struct MsmShape {
         if (c > 20) c = 20;
         W = 254 / c + 1; nb = 1u << (c - 1);
         seg = MSM_SEG_MIN;
-        while (seg < 4096 && (uint64_t)seg * nb * MSM_SEG_PER_BUCKET < max_entries()) seg <<= 1;
+        uint32_t spb = MSM_SEG_PER_BUCKET;
+        if (const char *e = getenv("ZK_SEG_PER_BUCKET")) { int v = atoi(e); if (v > 0) spb = (uint32_t)v; }   // tuning aid
+        while (seg < 4096 && (uint64_t)seg * nb * spb < max_entries()) seg <<= 1;
     }
     uint64_t max_entries() const { return (uint64_t)n * W; }
     uint64_t max_segments() const { return max_entries() / seg + nb + 1; }
@@ -98,8 +101,9 @@ struct MsmWork {
     void release();
     // table <- window multiples of d_bases[0..n) (device pointer); once per context
     int precompute(const typename C::Affine *d_bases, uint32_t n, hipStream_t st);
-    // enqueue the whole MSM on `st`; the result lands in host_result after the stream drains
-    int enqueue(const fe *scalars, const uint32_t *gather, uint32_t n, int canonical, hipStream_t st);
+    // enqueue the MSM: sort + accumulation (machine-filling) on `st`, the low-parallelism bucket reduction on
+    // `st_tail` (may equal st); the result lands in host_result after st_tail drains
+    int enqueue(const fe *scalars, const uint32_t *gather, uint32_t n, int canonical, hipStream_t st, hipStream_t st_tail);
     typename C::XYZZ finish() const { return *host_result; }
 };
 

@@ -382,7 +382,7 @@ int MsmWork<C>::precompute(const typename C::Affine *d_bases, uint32_t n, hipStr
 }
 
 template <class C>
-int MsmWork<C>::enqueue(const fe *scalars, const uint32_t *gather, uint32_t n, int canonical, hipStream_t st) {
+int MsmWork<C>::enqueue(const fe *scalars, const uint32_t *gather, uint32_t n, int canonical, hipStream_t st, hipStream_t st_tail) {
     if (n != table_n) return ZK_ERR_ARG;                        // the table stride is the precompute-time n
     const uint32_t c = sh.c, W = sh.W, nb = sh.nb, seg = sh.seg;
     const uint32_t K = nb < MSM_GROUP ? nb : MSM_GROUP, groups = nb / K;
@@ -406,6 +406,7 @@ int MsmWork<C>::enqueue(const fe *scalars, const uint32_t *gather, uint32_t n, i
     ZK_LAUNCH(k_msm_accumulate<C>, zk_div_up(max_seg, 64), 64, st, (const typename C::Affine *)table, (const uint32_t *)sorted,
               (const uint32_t *)off, (const uint32_t *)segoff, nb, seg, segsum);
     ZK_HIP(hipEventRecord(ev_acc1, st));
+    if (st_tail != st) { ZK_HIP(hipStreamWaitEvent(st_tail, ev_acc1, 0)); st = st_tail; }
     ZK_LAUNCH(k_msm_bucket_finalize<C>, zk_div_up(nb, 64), 64, st, (const typename C::XYZZ *)segsum,
               (const uint32_t *)segoff, nb, bucket, heavy_list, heavy_count);
     ZK_LAUNCH_SYNC(k_msm_heavy<C>, MSM_HEAVY_GRID, 128, st, (const typename C::XYZZ *)segsum, (const uint32_t *)segoff,

@@ -292,6 +292,7 @@ Range shard_range(uint32_t n, uint32_t rank, uint32_t count) {
 struct zk_ctx {
     int device = 0;
     bool serial = false;
+    bool in_flight = false;
     uint32_t nC = 0, nIn = 0, V = 0, m = 0, logm = 0;
     zk_config cfg{};
     G1::Affine alpha_g1; G2::Affine beta_g2;
@@ -306,7 +307,7 @@ struct zk_ctx {
     MsmWork<G1> mA, mH, mL; MsmWork<G2> mB;
     hipStream_t s_main = nullptr, s_a = nullptr, s_b = nullptr, s_l = nullptr;
     hipEvent_t ev_start = nullptr, ev_w = nullptr, ev_h = nullptr, ev_a0 = nullptr, ev_a1 = nullptr, ev_b0 = nullptr, ev_b1 = nullptr,
-               ev_l0 = nullptr, ev_l1 = nullptr, ev_h1 = nullptr;
+               ev_l0 = nullptr, ev_l1 = nullptr, ev_h1 = nullptr, ev_h0 = nullptr;
     ~zk_ctx() {
         hipSetDevice(device);
         void *dev[] = {dA_idx, dB_idx, d_w, d_a, d_b, d_c, d_t};
@@ -319,7 +320,7 @@ struct zk_ctx {
         if (serial) s_a = s_b = s_l = nullptr;
         hipStream_t ss[] = {s_main, s_a, s_b, s_l};
         for (auto s : ss) if (s) hipStreamDestroy(s);
-        hipEvent_t ee[] = {ev_start, ev_w, ev_h, ev_a0, ev_a1, ev_b0, ev_b1, ev_l0, ev_l1, ev_h1};
+        hipEvent_t ee[] = {ev_start, ev_w, ev_h, ev_a0, ev_a1, ev_b0, ev_b1, ev_l0, ev_l1, ev_h1, ev_h0};
         for (auto e : ee) if (e) hipEventDestroy(e);
     }
 };
@@ -377,10 +378,10 @@ static int ctx_build(zk_ctx *c, const zk_pk *pk, const zk_csr *A, const zk_csr *
     if (c->serial) { c->s_a = c->s_b = c->s_l = c->s_main; }
     else {
         ZK_HIP(hipStreamCreateWithPriority(&c->s_a, hipStreamNonBlocking, prio_lo));
-        ZK_HIP(hipStreamCreateWithPriority(&c->s_b, hipStreamNonBlocking, prio_lo));
+        ZK_HIP(hipStreamCreateWithPriority(&c->s_b, hipStreamNonBlocking, prio_hi));
         ZK_HIP(hipStreamCreateWithPriority(&c->s_l, hipStreamNonBlocking, prio_lo));
     }
-    hipEvent_t *ee[] = {&c->ev_start, &c->ev_w, &c->ev_h, &c->ev_a0, &c->ev_a1, &c->ev_b0, &c->ev_b1, &c->ev_l0, &c->ev_l1, &c->ev_h1};
+    hipEvent_t *ee[] = {&c->ev_start, &c->ev_w, &c->ev_h, &c->ev_a0, &c->ev_a1, &c->ev_b0, &c->ev_b1, &c->ev_l0, &c->ev_l1, &c->ev_h1, &c->ev_h0};
     for (auto e : ee) ZK_HIP(hipEventCreate(e));
     ZK_TRY(ntt_tables_create(c->tab, c->logm, c->s_main));
     ZK_HIP(hipStreamSynchronize(c->s_main));
@@ -447,27 +448,39 @@ static int upload_witness(zk_ctx *c, const uint64_t *witness, int canonical) {
 static void store_xyzz(uint64_t *dst, const G1::XYZZ &p) { memcpy(dst, &p, sizeof(p)); }
 static void store_xyzz(uint64_t *dst, const G2::XYZZ &p) { memcpy(dst, &p, sizeof(p)); }
 
-static int prove_partial_impl(zk_ctx *c, const uint64_t *witness, int canonical, zk_partials *out, zk_timings *tm) {
-    if (!c || !witness || !out) return fail(ZK_ERR_ARG, "null argument");
+static int prove_submit_impl(zk_ctx *c, const uint64_t *witness, int canonical) {
+    if (!c || !witness) return fail(ZK_ERR_ARG, "null argument");
+    if (c->in_flight) return fail(ZK_ERR_ARG, "a proof is already in flight on this context (collect it first)");
     ZK_TRY(use_device(c->device));
     ZK_TRY(upload_witness(c, witness, canonical));
-    // A-, B-, L-query only need the witness: run them beside the H pipeline on their own streams
-    ZK_HIP(hipStreamWaitEvent(c->s_a, c->ev_w, 0));
-    ZK_HIP(hipStreamWaitEvent(c->s_b, c->ev_w, 0));
-    ZK_HIP(hipStreamWaitEvent(c->s_l, c->ev_w, 0));
-    ZK_HIP(hipEventRecord(c->ev_a0, c->s_a));
-    ZK_TRY(c->mA.enqueue(c->d_w, c->dA_idx, c->rA.n(), 0, c->s_a));              // tcc:488-495
-    ZK_HIP(hipEventRecord(c->ev_a1, c->s_a));
-    ZK_HIP(hipEventRecord(c->ev_b0, c->s_b));
-    ZK_TRY(c->mB.enqueue(c->d_w, c->dB_idx, c->rB.n(), 0, c->s_b));              // tcc:499-506
+    // One in-order stream carries every machine-filling kernel (sorts, accumulations, the H pipeline) so that
+    // none of them is stretched by contention; the low-parallelism bucket reductions ("tails") of the B-, A-
+    // and L-query run on side streams beside the next accumulation.  Longest tail (G2) first; the H-query is
+    // last and keeps its tail on the main stream.
+    hipStream_t m = c->s_main;
+    ZK_HIP(hipEventRecord(c->ev_b0, m));
+    ZK_TRY(c->mB.enqueue(c->d_w, c->dB_idx, c->rB.n(), 0, m, c->s_b));                          // tcc:499-506
     ZK_HIP(hipEventRecord(c->ev_b1, c->s_b));
-    ZK_HIP(hipEventRecord(c->ev_l0, c->s_l));
-    ZK_TRY(c->mL.enqueue(c->d_w + (c->nIn + 1) + c->rL.lo, nullptr, c->rL.n(), 0, c->s_l));   // tcc:522-530
+    ZK_HIP(hipEventRecord(c->ev_a0, m));
+    ZK_TRY(c->mA.enqueue(c->d_w, c->dA_idx, c->rA.n(), 0, m, c->s_a));                          // tcc:488-495
+    ZK_HIP(hipEventRecord(c->ev_a1, c->s_a));
+    ZK_HIP(hipEventRecord(c->ev_l0, m));
+    ZK_TRY(c->mL.enqueue(c->d_w + (c->nIn + 1) + c->rL.lo, nullptr, c->rL.n(), 0, m, c->s_l)); // tcc:522-530
     ZK_HIP(hipEventRecord(c->ev_l1, c->s_l));
+    ZK_HIP(hipEventRecord(c->ev_h0, m));
     ZK_TRY(enqueue_compute_h(c));
-    ZK_HIP(hipEventRecord(c->ev_h, c->s_main));
-    ZK_TRY(c->mH.enqueue(c->d_t + c->rH.lo, nullptr, c->rH.n(), 0, c->s_main));  // tcc:510-518
-    ZK_HIP(hipEventRecord(c->ev_h1, c->s_main));
+    ZK_HIP(hipEventRecord(c->ev_h, m));
+    ZK_TRY(c->mH.enqueue(c->d_t + c->rH.lo, nullptr, c->rH.n(), 0, m, m));                      // tcc:510-518
+    ZK_HIP(hipEventRecord(c->ev_h1, m));
+    c->in_flight = true;
+    return ZK_OK;
+}
+
+static int prove_collect_impl(zk_ctx *c, zk_partials *out, zk_timings *tm) {
+    if (!c || !out) return fail(ZK_ERR_ARG, "null argument");
+    if (!c->in_flight) return fail(ZK_ERR_ARG, "no proof in flight on this context");
+    ZK_TRY(use_device(c->device));
+    c->in_flight = false;
     ZK_HIP(hipStreamSynchronize(c->s_a)); ZK_HIP(hipStreamSynchronize(c->s_b));
     ZK_HIP(hipStreamSynchronize(c->s_l)); ZK_HIP(hipStreamSynchronize(c->s_main));
     if (!Fr::is_zero(*c->h_tail)) return fail(ZK_ERR_DEGREE, "h[m-1] != 0: the witness does not satisfy the constraint system");
@@ -477,7 +490,7 @@ static int prove_partial_impl(zk_ctx *c, const uint64_t *witness, int canonical,
     if (tm) {
         memset(tm, 0, sizeof(*tm));
         hipEventElapsedTime(&tm->h2d_witness, c->ev_start, c->ev_w);
-        hipEventElapsedTime(&tm->compute_h, c->ev_w, c->ev_h);
+        hipEventElapsedTime(&tm->compute_h, c->ev_h0, c->ev_h);
         hipEventElapsedTime(&tm->a_query, c->ev_a0, c->ev_a1);
         hipEventElapsedTime(&tm->b_query, c->ev_b0, c->ev_b1);
         hipEventElapsedTime(&tm->l_query, c->ev_l0, c->ev_l1);
@@ -493,6 +506,16 @@ static int prove_partial_impl(zk_ctx *c, const uint64_t *witness, int canonical,
     }
     return ZK_OK;
 }
+
+
+static int prove_partial_impl(zk_ctx *c, const uint64_t *witness, int canonical, zk_partials *out, zk_timings *tm) {
+    if (!out) return fail(ZK_ERR_ARG, "null argument");
+    ZK_TRY(prove_submit_impl(c, witness, canonical));
+    return prove_collect_impl(c, out, tm);
+}
+// asynchronous form: enqueue a proof and return; collect later (lets two contexts keep the GPU full)
+extern "C" int zk_prove_submit(zk_ctx *ctx, const uint64_t *witness, int canonical) { return prove_submit_impl(ctx, witness, canonical); }
+extern "C" int zk_prove_collect(zk_ctx *ctx, zk_partials *out, zk_timings *t) { return prove_collect_impl(ctx, out, t); }
 
 template <class F> static void canon4(uint64_t dst[4], const fe &mont) { fe c = F::from_mont(mont); memcpy(dst, c.l, 32); }
 static void put_g1(const G1::XYZZ &p, uint64_t x[4], uint64_t y[4], uint32_t *inf) {
@@ -783,7 +806,7 @@ static int msm_host(const uint64_t *bases, const uint64_t *scalars, uint32_t n, 
     if (rc == ZK_OK) rc = dev_upload(&d_scalars, (const fe *)scalars, n);
     if (rc == ZK_OK) rc = work.alloc(n, cbits);
     if (rc == ZK_OK) rc = work.precompute(d_bases, n, nullptr);
-    if (rc == ZK_OK) rc = work.enqueue(d_scalars, nullptr, n, 0, nullptr);
+    if (rc == ZK_OK) rc = work.enqueue(d_scalars, nullptr, n, 0, nullptr, nullptr);
     if (rc == ZK_OK && hipDeviceSynchronize() != hipSuccess) rc = fail(ZK_ERR_HIP, "MSM kernels failed");
     if (rc == ZK_OK) {
         typename C::Affine a = C::to_affine(work.finish());

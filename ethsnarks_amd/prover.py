@@ -59,7 +59,7 @@ EXPORTS = [
     "zk_pk_load_raw", "zk_pk_save_raw", "zk_pk_from_parts", "zk_pk_sizes", "zk_pk_part", "zk_pk_free",
     "zk_keygen", "zk_vk_to_json", "zk_vk_free",
     "zk_domain_size", "zk_ctx_create", "zk_ctx_destroy",
-    "zk_prove", "zk_prove_timed", "zk_prove_partial", "zk_prove_partial_timed", "zk_prove_combine", "zk_proof_to_json",
+    "zk_prove", "zk_prove_timed", "zk_prove_partial", "zk_prove_partial_timed", "zk_prove_combine", "zk_prove_submit", "zk_prove_collect", "zk_proof_to_json",
     "zk_ntt", "zk_witness_map", "zk_msm_g1", "zk_msm_g2", "zk_field_mul",
 ]
 
@@ -283,6 +283,17 @@ class ProverContext:
             return np.frombuffer(bytes(part), dtype=np.uint64).copy(), t.as_dict()
         _check(_lib.zk_prove_partial(self._h, _p64(w), int(canonical), C.byref(part)))
         return np.frombuffer(bytes(part), dtype=np.uint64).copy()      # 80 u64 = 640 bytes
+
+    def submit(self, witness, canonical=False):
+        """enqueue a proof and return (zk_prove_submit); the witness is copied to pinned memory first"""
+        w = self._w(witness)
+        _check(_lib.zk_prove_submit(self._h, _p64(w), int(canonical)))
+
+    def collect(self):
+        """wait for the submitted proof: (partials[80 u64], timings dict)"""
+        part, t = ZkPartials(), ZkTimings()
+        _check(_lib.zk_prove_collect(self._h, C.byref(part), C.byref(t)))
+        return np.frombuffer(bytes(part), dtype=np.uint64).copy(), t.as_dict()
 
     def prove_combine(self, partials):
         arr = _c64(partials).reshape(-1, 80)

@@ -135,6 +135,11 @@ int zk_prove_timed(zk_ctx *ctx, const uint64_t *witness, int canonical, zk_proof
 int zk_prove_partial(zk_ctx *ctx, const uint64_t *witness, int canonical, zk_partials *out);
 int zk_prove_partial_timed(zk_ctx *ctx, const uint64_t *witness, int canonical, zk_partials *out, zk_timings *t);
 int zk_prove_combine(const zk_ctx *ctx, const zk_partials *parts, uint32_t count, zk_proof *out);
+/* asynchronous form of zk_prove_partial: submit enqueues the whole proof on the context's streams and returns;
+ * collect waits for it.  One proof in flight per context; several contexts keep the GPU full (ProverContext is
+ * per concurrent prover in the reference too, hpp:279-291). */
+int zk_prove_submit(zk_ctx *ctx, const uint64_t *witness, int canonical);
+int zk_prove_collect(zk_ctx *ctx, zk_partials *out, zk_timings *t);
 
 /* inputs: nIn Fr elements = witness[1..nIn] (Montgomery unless canonical); returns the JSON length
  * (excluding NUL) through *len; ZK_ERR_BUFFER if cap is too small (len still set) */
