@@ -340,10 +340,6 @@ struct Curve {
         r.ZZ = F::mul(V, p.ZZ); r.ZZZ = F::mul(W, p.ZZZ);
         return r;
     }
-    // the doubling branches of madd/add are taken only when both operands are the same point: keep
-    // them out of line so the hot loop's code (and its register allocation) stays small
-    static ZK_HD_NOINLINE XYZZ dbl_affine_slow(const Affine &p) { return dbl_affine(p); }
-    static ZK_HD_NOINLINE XYZZ dbl_slow(const XYZZ &p) { return dbl(p); }
     // p + q, q affine (madd-2008-s); all exceptional cases handled -- bit-exactness needs them
     static ZK_HD XYZZ madd(const XYZZ &p, const Affine &q) {
         if (is_inf(q)) return p;
@@ -351,7 +347,7 @@ struct Curve {
         E U2 = F::mul(q.x, p.ZZ), S2 = F::mul(q.y, p.ZZZ);
         E Pd = F::sub(U2, p.X), R = F::sub(S2, p.Y);
         if (F::is_zero(Pd)) {
-            if (F::is_zero(R)) return dbl_affine_slow(q);
+            if (F::is_zero(R)) return dbl_affine(q);
             return infinity();
         }
         E PP = F::sqr(Pd), PPP = F::mul(Pd, PP), Q = F::mul(p.X, PP);
@@ -369,7 +365,7 @@ struct Curve {
         E S1 = F::mul(p.Y, q.ZZZ), S2 = F::mul(q.Y, p.ZZZ);
         E Pd = F::sub(U2, U1), R = F::sub(S2, S1);
         if (F::is_zero(Pd)) {
-            if (F::is_zero(R)) return dbl_slow(p);
+            if (F::is_zero(R)) return dbl(p);
             return infinity();
         }
         E PP = F::sqr(Pd), PPP = F::mul(Pd, PP), Q = F::mul(U1, PP);
