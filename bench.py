@@ -169,9 +169,10 @@ def main():
                        "multi_exp_c": args.multi_exp_c or P_pick_c(nB_local), "witness": "host buffer, H2D inside the timed region", "inflight": len(ctxs)},
             "roofline": {"kernel": "k_msm_accumulate<G2> (B-query bucket accumulation)", "bound": "hbm",
                          "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": pmc_traffic("k_msm_accumulate<G2>", world if shard else 1),
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(kern_ms, 4),
-                         "note": "VALU-integer bound kernel (no dense contraction, no MFMA): see valu"},
+                         "note": "VALU-integer bound kernel (no dense contraction, no MFMA): see valu. traffic > algorithmic bytes by design: "
+                                 "each base is read through its W window multiples (msm.hpp), trading HBM bytes for 16x fewer bucket reductions"},
             "valu": {"kernel": "k_msm_accumulate<G2>", "unit": "G Fq-mul/s", "achieved": round(fq_muls / (kern_ms * 1e-3) / 1e9, 3) if kern_ms > 0 else 0.0,
                      "peak": round(MAD_LANE_OPS_PER_CLK_CU * 256 * 2.4 / FQ_MUL_MADS, 1),
                      "peak_basis": "measured v_mad_u64_u32 issue rate x 256 CU x 2.4 GHz / 136 mads per Montgomery product"},
@@ -188,6 +189,16 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
+
+
+def pmc_traffic(kernel, shards):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (2 x FETCH_SIZE + WRITE_SIZE, collected with
+    rocprofv3 --pmc in separate runs, tools/pmc_summary.py); valid for the unsharded 2^20 workload only."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        return d["kernels"][kernel]["hbm_bytes_per_launch"] if shards == 1 else None
+    except Exception:
+        return None
 
 
 def P_pick_c(n):
