@@ -147,3 +147,59 @@ def test_errors(hip, oracle, tmp_path):
     with pytest.raises(hip.ZkError) as e:
         hip.load_proving_key(str(tmp_path / "nope.raw"))
     assert e.value.code == 2
+
+
+def test_config4_merkle_membership_depth29(hip, oracle):
+    """BASELINE config 4: merkle_path_authenticator<MiMC_e7_hash_gadget>, depth 29, 21 345 constraints, m = 2^15;
+    key from the GPU generator, proof byte-identical to the oracle and accepted by the pinned verifier"""
+    import pyref
+    from ethsnarks_amd import gadgets as G
+    r, w, root = G.merkle_membership_circuit(29)
+    assert root == 14972246236048249827985830600768475898195156734731557762844426864943654467818
+    wm = F.fr_to_mont(w)
+    pk, vk = hip.keygen(r, seed=29)
+    pk_o, vk_o = oracle.keygen(r, seed=29)
+    assert vk.to_json() == vk_o.to_json()                                   # GPU keygen == oracle keygen
+    P1, P2 = pk.parts(), pk_o.parts()
+    assert all(np.array_equal(np.asarray(P1[k]), np.asarray(P2[k])) for k in P1)
+    ctx = hip.ProverContext(pk, r)
+    got = hip.prove(ctx, wm)
+    expect, _ = oracle.prove(pk_o, r, wm)
+    assert got == expect
+    proof = json.loads(got)
+    assert int(proof["input"][0], 16) == root
+    assert pyref.verify(json.loads(vk.to_json()), proof)
+    # a different leaf position: address bits / selector products are 0/1-valued witness entries
+    r2, w2, _ = G.merkle_membership_circuit(29, leaf=12345, address=0x15555555, path=[G.merkle_unique(d, 7) for d in range(29)])
+    expect2, _ = oracle.prove(pk_o, r2, F.fr_to_mont(w2))                   # same constraint system, same key
+    assert hip.prove(ctx, F.fr_to_mont(w2)) == expect2
+
+
+def test_config2_chain_2pow18_gpu_keygen(hip, oracle, tmp_path):
+    """BASELINE config 2: synthetic chain, 2^18 constraints, real key from zk_keygen via the .raw file,
+    proof bit-exact vs the CPU oracle on the same key"""
+    logm = 18
+    r, w = R.synthetic_chain((1 << logm) - 2, 1)
+    wm = F.fr_to_mont(w)
+    pk_path, vk_path = str(tmp_path / "pk.raw"), str(tmp_path / "vk.json")
+    assert hip.stub_genkeys_from_pb(r, pk_path, vk_path, seed=18) == 0
+    pk = hip.load_proving_key(pk_path)
+    pk_o = oracle.read_raw(pk_path)                                          # the oracle reads the file the GPU side wrote
+    ctx = hip.ProverContext(pk, r)
+    expect, _ = oracle.prove(pk_o, r, wm)
+    assert hip.prove(ctx, wm) == expect
+
+
+def test_async_submit_collect_two_contexts(hip, oracle):
+    r, w = R.synthetic_chain((1 << 12) - 2, 1)
+    wm = F.fr_to_mont(w)
+    pk_o, _ = oracle.keygen(r, seed=5)
+    expect, _ = oracle.prove(pk_o, r, wm)
+    pk = hip.ProvingKey.from_parts(**pk_o.parts())
+    a, b = hip.ProverContext(pk, r), hip.ProverContext(pk, r)
+    a.submit(wm); b.submit(wm)
+    with pytest.raises(hip.ZkError):
+        a.submit(wm)                                                         # one proof in flight per context
+    for c in (a, b):
+        part, _ = c.collect()
+        assert hip.proof_to_json(c.prove_combine(part), wm[1:2]) == expect
