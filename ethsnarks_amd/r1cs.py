@@ -171,3 +171,36 @@ def random_r1cs(nC, nIn, n_extra_vars=3, max_terms=4, seed=1, small_values=False
         w.append(rng.fr())
     V = len(w) - 1
     return R1CS(nC, nIn, V, CSR.from_rows(A), CSR.from_rows(B), CSR.from_rows(C)), w
+
+
+# --------------------------------------------------------------------------------------------------
+# The reference's circuit / witness dumps (src/export.cpp:157-221): an existing ethsnarks binary can write its
+# protoboard with r1cs2json / witness2json and this backend proves it without linking libsnark.
+def r1cs_to_json(r):
+    """exact text of r1cs2json (src/export.cpp:173-206); nVars counts the constant ONE"""
+    def lc(row):
+        return "{" + ",".join('"%d": "%d"' % (i, c) for i, c in row) + "}"
+    A, B, C = r.A.to_rows(), r.B.to_rows(), r.C.to_rows()
+    s = "{\n \"nPubInputs\": %d,\n \"nOutputs\": 0,\n \"nVars\": %d,\n \"nConstraints\": %d,\n \"constraints\": [\n" % (r.nIn, r.V + 1, r.nC)
+    for j in range(r.nC):
+        s += "  [" + lc(A[j]) + "," + lc(B[j]) + "," + lc(C[j]) + ("]\n" if j == r.nC - 1 else "],\n")
+    return s + " ]\n}"
+
+
+def r1cs_from_json(text):
+    import json
+    d = json.loads(text)
+    rows = lambda k: [[(int(i), int(c)) for i, c in con[k].items()] for con in d["constraints"]]
+    nC = int(d["nConstraints"])
+    assert nC == len(d["constraints"])
+    return R1CS(nC, int(d["nPubInputs"]), int(d["nVars"]) - 1, CSR.from_rows(rows(0)), CSR.from_rows(rows(1)), CSR.from_rows(rows(2)))
+
+
+def witness_to_json(w_ints):
+    """exact text of witness2json (src/export.cpp:208-221): decimal strings, index 0 is ONE"""
+    return "[\n" + ",\n".join(' "%d"' % v for v in w_ints) + "\n]"
+
+
+def witness_from_json(text):
+    import json
+    return [int(v) % FR for v in json.loads(text)]

@@ -108,3 +108,17 @@ def test_synthetic_chain_shape():
     assert r.A.nnz == 15 * 2 + 14 + 31 and r.B.nnz == 29 + 31 and r.C.nnz == 30
     r2, _ = R.synthetic_chain((1 << 10) - 2, 1)
     assert r2.domain_size == 1 << 10
+
+
+def test_r1cs_and_witness_json_dumps_roundtrip():
+    """schema of src/export.cpp:157-221 (r1cs2json / witness2json)"""
+    from ethsnarks_amd import gadgets as G
+    r, w, _ = G.merkle_membership_circuit(1, leaf=5, address=1, path=[7])      # general coefficients, unique indices per row
+    txt = R.r1cs_to_json(r)
+    assert txt.startswith('{\n "nPubInputs": 1,\n "nOutputs": 0,\n "nVars": %d,\n "nConstraints": 737,\n "constraints": [\n  [{' % (r.V + 1))
+    r2 = R.r1cs_from_json(txt)
+    assert (r2.nC, r2.nIn, r2.V) == (r.nC, r.nIn, r.V)
+    assert r2.A.to_rows() == r.A.to_rows() and r2.B.to_rows() == r.B.to_rows() and r2.C.to_rows() == r.C.to_rows()
+    wt = R.witness_to_json(w)
+    assert wt.startswith('[\n "1",\n "') and R.witness_from_json(wt) == w
+    assert r2.is_satisfied(R.witness_from_json(wt))
