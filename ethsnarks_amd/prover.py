@@ -60,6 +60,7 @@ EXPORTS = [
     "zk_keygen", "zk_vk_to_json", "zk_vk_free",
     "zk_domain_size", "zk_ctx_create", "zk_ctx_destroy",
     "zk_prove", "zk_prove_timed", "zk_prove_partial", "zk_prove_partial_timed", "zk_prove_combine", "zk_prove_submit", "zk_prove_collect", "zk_proof_to_json",
+    "zk_verify",
     "zk_ntt", "zk_witness_map", "zk_msm_g1", "zk_msm_g2", "zk_field_mul",
 ]
 
@@ -348,6 +349,24 @@ def stub_prove_from_pb(r1cs, witness, pk_file, **kw):
     finally:
         ctx.close()
         pk.close()
+
+
+def stub_verify(vk_json, proof_json):
+    """ethsnarks::stub_verify (src/stubs.cpp:16-33): True iff the proof verifies under the key (host code)."""
+    ok = C.c_int(0)
+    _check(load_library(_lib_path_loaded).zk_verify(vk_json.encode(), proof_json.encode(), C.byref(ok)))
+    return ok.value == 1
+
+
+def stub_test_proof_verify(r1cs, witness, **kw):
+    """ethsnarks::stub_test_proof_verify (src/stubs.cpp:135-148): keygen -> prove -> verify in memory,
+    with the context fully initialised (the reference forgets constraint_system and domain)."""
+    pk, vk = keygen(r1cs, **kw)
+    ctx = ProverContext(pk, r1cs)
+    try:
+        return stub_verify(vk.to_json(), prove(ctx, witness))
+    finally:
+        ctx.close()
 
 
 # ---- kernel-level entry points

@@ -15,6 +15,7 @@
  *   zk_keygen           <- r1cs_gg_ppzksnark_zok_generator + nozk conversion  tcc:277-449, hpp:209-233
  *                          (stub_genkeys_from_pb, src/stubs.cpp:77-87)
  *   zk_vk_to_json       <- vk2json                                            src/export.cpp:124-145
+ *   zk_verify / ethsnarks_verify <- stub_verify / ethsnarks_verify          src/stubs.cpp:16-33, src/verify_dll.cpp:3-10
  *
  * Plain C types only.  Field elements are 4 x u64 little-endian limbs; "Montgomery" means the
  * libff::Fp_model<4> in-memory form (value * 2^256 mod p), which is what `pb.values` and the `.raw`
@@ -27,6 +28,7 @@
  */
 #ifndef ZKHIP_H
 #define ZKHIP_H
+#include <stdbool.h>
 #include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
@@ -145,6 +147,12 @@ int zk_prove_collect(zk_ctx *ctx, zk_partials *out, zk_timings *t);
  * (excluding NUL) through *len; ZK_ERR_BUFFER if cap is too small (len still set) */
 int zk_proof_to_json(const zk_proof *proof, const uint64_t *inputs, uint32_t nIn, int canonical,
                      char *buf, size_t cap, size_t *len);
+
+/* ---- verifier (host code, as in the reference): r1cs_gg_ppzksnark_zok_verifier_strong_IC
+ * (tcc:552-670) behind stub_verify (src/stubs.cpp:16-33).  *accepted = 1 iff the proof verifies. */
+int zk_verify(const char *vk_json, const char *proof_json, int *accepted);
+/* same symbol and signature as the reference's libethsnarks_verify (src/verify_dll.cpp:3-10) */
+bool ethsnarks_verify(const char *vk_json, const char *proof_json);
 
 /* ---- kernel-level entry points (parity tests / micro-benchmarks); host buffers in and out */
 int zk_ntt(uint64_t *data, uint32_t logm, int inverse, int coset, int device);

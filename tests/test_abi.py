@@ -13,7 +13,7 @@ LIB = os.path.join(ROOT, "ethsnarks_amd", "libzkhip.so")
 def declared_symbols():
     hdr = open(os.path.join(ROOT, "include", "zkhip.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    return sorted(set(re.findall(r"\b(zk_[a-z0-9_]+)\s*\(", hdr)))
+    return sorted(set(re.findall(r"\b(zk_[a-z0-9_]+)\s*\(", hdr)))          # + ethsnarks_verify, checked below
 
 
 def test_header_symbols_are_bound_in_python():
@@ -26,6 +26,7 @@ def test_library_exports_every_declared_symbol():
     L = C.CDLL(LIB)
     for name in declared_symbols():
         assert hasattr(L, name), name
+    assert hasattr(L, "ethsnarks_verify")              # the reference's own verify symbol (src/verify_dll.cpp:3-10)
     L.zk_version.restype = C.c_char_p
     assert b"gfx950" in L.zk_version()
 

@@ -122,3 +122,23 @@ def test_errors(zk, oracle, tmp_path):
     with pytest.raises(zk.ZkError) as e:
         zk.load_proving_key(str(p))
     assert e.value.code == 3                                   # ZK_ERR_FORMAT
+
+
+def test_verifier_on_reference_static_triple(zk):
+    """the product's C++ verifier is pinned directly on the reference's static (vk, proof) vector"""
+    import json, os
+    from helpers import GOLDEN
+    d = json.load(open(os.path.join(GOLDEN, "ref_static_triple.json")))
+    assert zk.stub_verify(json.dumps(d["vk"]), json.dumps(d["proof"]))
+    bad = dict(d["proof"]); bad["input"] = [bad["input"][0], "0x8"]
+    assert not zk.stub_verify(json.dumps(d["vk"]), json.dumps(bad))
+    assert not zk.stub_verify(json.dumps(d["vk"]), json.dumps(dict(d["proof"], A=d["proof"]["C"])))
+    assert not zk.stub_verify(json.dumps(d["vk"]), json.dumps(dict(d["proof"], input=d["proof"]["input"][:1])))
+    with pytest.raises(zk.ZkError):
+        zk.stub_verify("{}", json.dumps(d["proof"]))
+
+
+def test_stub_test_proof_verify_roundtrip(zk):
+    """keygen -> prove -> verify entirely through the C ABI (src/stubs.cpp:135-148)"""
+    r, w = R.random_r1cs(20, 2, seed=8)
+    assert zk.stub_test_proof_verify(r, F.fr_to_mont(w), seed=3)

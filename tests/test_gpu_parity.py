@@ -169,6 +169,7 @@ def test_config4_merkle_membership_depth29(hip, oracle):
     proof = json.loads(got)
     assert int(proof["input"][0], 16) == root
     assert pyref.verify(json.loads(vk.to_json()), proof)
+    assert hip.stub_verify(vk.to_json(), got)                              # the product's own verifier (zk_verify)
     # a different leaf position: address bits / selector products are 0/1-valued witness entries
     r2, w2, _ = G.merkle_membership_circuit(29, leaf=12345, address=0x15555555, path=[G.merkle_unique(d, 7) for d in range(29)])
     expect2, _ = oracle.prove(pk_o, r2, F.fr_to_mont(w2))                   # same constraint system, same key
@@ -233,3 +234,14 @@ def test_config3_chain_2pow20_headline(hip, oracle):
         c.close()
     ctx = hip.ProverContext(pk, r, shard_rank=0, shard_count=4)
     assert hip.proof_to_json(ctx.prove_combine(np.stack(shards)), wm[1:2]) == expect
+
+
+def test_stub_test_proof_verify_and_static_triple(hip):
+    """stub_test_proof_verify (src/stubs.cpp:135-148) through the C ABI on the GPU; zk_verify on the reference's vector"""
+    import os
+    from helpers import GOLDEN
+    r, w = R.random_r1cs(200, 3, seed=21)
+    assert hip.stub_test_proof_verify(r, F.fr_to_mont(w), seed=2)
+    d = json.load(open(os.path.join(GOLDEN, "ref_static_triple.json")))
+    assert hip.stub_verify(json.dumps(d["vk"]), json.dumps(d["proof"]))
+    assert not hip.stub_verify(json.dumps(d["vk"]), json.dumps(dict(d["proof"], C=d["proof"]["A"])))
