@@ -7,6 +7,8 @@
 //   ethsnarks::stub_genkeys_from_pb(pb, pk_file, vk_file)         src/stubs.hpp:16,  src/stubs.cpp:77-87
 //   ethsnarks::stub_prove_from_pb(pb, pk_raw)                     upstream wrapper, src/pinocchio/main.cpp:10,41
 //   ethsnarks::stub_main_prove<GadgetT>(prog, argc, argv)         CLI helper shaped like stub_main_genkeys, src/stubs.hpp:36-55
+//   ethsnarks::stub_verify(vk_json, proof_json)                   src/stubs.hpp:10,  src/stubs.cpp:16-33
+//   ethsnarks::stub_test_proof_verify(pb)                         src/stubs.hpp:14,  src/stubs.cpp:135-148 (context fully initialised)
 //
 // so that a gadget binary written against ethsnarks keeps its source: it includes this header instead of
 // "stubs.hpp" and links libzkhip.so instead of libsnark's prover.  The libsnark *front end* (protoboard,
@@ -21,6 +23,8 @@
 #include <zkhip.h>
 
 #include <cstdint>
+#include <cstdio>
+#include <iterator>
 #include <cstring>
 #include <fstream>
 #include <iostream>
@@ -60,6 +64,13 @@ struct zk_error : std::runtime_error {
     zk_error(int c) : std::runtime_error(std::string(zk_strerror(c)) + ": " + zk_last_error()), code(c) {}
 };
 inline void zk_check(int rc) { if (rc != ZK_OK) throw zk_error(rc); }
+
+// stub_verify (src/stubs.cpp:16-33): needs no libsnark types at all
+inline bool stub_verify(const char *vk_json, const char *proof_json) {
+    int ok = 0;
+    zk_check(zk_verify(vk_json, proof_json, &ok));      // malformed JSON throws, as the reference's parser does
+    return ok == 1;
+}
 
 // ProvingKeyT: owning handle of the nozk proving key (r1cs_gg_ppzksnark_zok_proving_key_nozk, hpp:171-274)
 class ProvingKeyT {
@@ -172,6 +183,18 @@ inline int stub_genkeys_from_pb(ProtoboardT &pb, const char *pk_file, const char
     if (rc == ZK_OK) rc = zk_pk_save_raw(pk, pk_file, ZK_CODEC_ALT_BN128);
     zk_pk_free(pk); zk_vk_free(vk);
     return rc == ZK_OK ? 0 : 1;
+}
+
+// stub_test_proof_verify (src/stubs.cpp:135-148): keygen -> prove -> verify in memory.  Unlike the reference it
+// sets up the whole context (the reference leaves constraint_system and domain unset).
+inline bool stub_test_proof_verify(ProtoboardT &pb) {
+    const std::string pk_tmp = std::string(std::tmpnam(nullptr)) + ".raw", vk_tmp = pk_tmp + ".vk.json";
+    if (stub_genkeys_from_pb(pb, pk_tmp.c_str(), vk_tmp.c_str()) != 0) return false;
+    std::ifstream vf(vk_tmp, std::ios::binary);
+    const std::string vk((std::istreambuf_iterator<char>(vf)), std::istreambuf_iterator<char>());
+    const std::string proof = stub_prove_from_pb(pb, pk_tmp.c_str());
+    std::remove(pk_tmp.c_str()); std::remove(vk_tmp.c_str());
+    return stub_verify(vk.c_str(), proof.c_str());
 }
 
 // stub_main_prove: argv helper shaped like stub_main_genkeys (src/stubs.hpp:36-55)
