@@ -21,8 +21,8 @@ namespace zk {
 
 constexpr int NTT_TILE_LOG = 11;                 // 2048 elements = 64 KiB of LDS per workgroup
 constexpr int NTT_TILE = 1 << NTT_TILE_LOG;
-constexpr int NTT_THREADS = 256;
-constexpr int NTT_MIN_LOGC = 3;                  // >= 8 columns = 256 contiguous bytes per tile row
+constexpr int NTT_THREADS = 512;
+constexpr int NTT_MIN_LOGC = 2;                  // >= 4 columns = 128 contiguous bytes (one cache line) per tile row
 
 static ZK_HD uint32_t bitrev32(uint32_t v, uint32_t bits) {
     uint32_t r = 0;
