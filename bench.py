@@ -13,7 +13,7 @@ all ranks / max-over-ranks time).  The MSM-sharded leg of north_star / BASELINE 
 reported under "msm_sharded": the base ranges of the key are split over the ranks, every rank proves its
 shard, the 640-byte partial results are exchanged with one RCCL all-gather and folded in rank order
 ("strong": the GPUs share each proof; the witness -> H pipeline is replicated).  --mode shard makes that
-leg the headline instead.  --inflight K (default 2) keeps K
+leg the headline instead.  --inflight K (default 3) keeps K
 prover contexts per GPU busy through the asynchronous zk_prove_submit / zk_prove_collect pair, so the next
 proof's witness upload and sort overlap the bucket-reduction tails of the current one; every step still
 completes a full proof, and --inflight 1 gives the one-proof-at-a-time latency figure.
@@ -44,7 +44,7 @@ def main():
     ap.add_argument("--logm", type=int, default=20, help="domain size 2^logm (nC = 2^logm - 2)")
     ap.add_argument("--mode", choices=["shard", "replicas"], default="replicas")
     ap.add_argument("--multi-exp-c", type=int, default=0)
-    ap.add_argument("--inflight", type=int, default=2,
+    ap.add_argument("--inflight", type=int, default=3,
                     help="prover contexts kept in flight per GPU (1 = one synchronous proof at a time; 2 overlaps the "
                          "next proof's upload/sort with the current proof's bucket-reduction tails)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -37,7 +37,6 @@ constexpr uint32_t MSM_SEG_PER_BUCKET = 16;   // target segments per bucket (set
 constexpr uint32_t MSM_HEAVY = 64;        // buckets with more segments than this are reduced by a workgroup
 constexpr uint32_t MSM_GROUP = 8;         // buckets per running-sum thread
 constexpr uint32_t MSM_TREE = 256;        // fan-in (= workgroup size) of the final tree sum
-constexpr uint32_t MSM_KEY_NONE = 0xffffffffu;
 #ifdef ZK_EMUL
 constexpr uint32_t MSM_HEAVY_GRID = 2;    // the emulator spawns a real thread per GPU thread
 #else
@@ -90,7 +89,7 @@ struct MsmWork {
     uint32_t table_n = 0;
     uint2 *pairs = nullptr;                     // pass-1 output of the bucket sort: (payload, bucket)
     uint32_t *counts = nullptr, *bin_total = nullptr, *bin_base = nullptr;
-    uint32_t *hist = nullptr, *off = nullptr, *segoff = nullptr, *cursor = nullptr, *sorted = nullptr;
+    uint32_t *hist = nullptr, *off = nullptr, *segoff = nullptr, *sorted = nullptr;
     uint32_t *heavy_list = nullptr, *heavy_count = nullptr, *tile_a = nullptr, *tile_b = nullptr;
     typename C::XYZZ *segsum = nullptr, *bucket = nullptr, *partial_a = nullptr, *partial_b = nullptr;
     typename C::XYZZ *host_result = nullptr;    // pinned, 1 entry

@@ -175,7 +175,7 @@ k_sort_fine(const uint2 *__restrict__ pairs, const uint32_t *__restrict__ bin_ba
 //   off[b]    = entries before bucket b          segoff[b] = fixed-length segments before bucket b
 // k_msm_scan_local: each workgroup scans SCAN_TILE counters (thread-serial runs + LDS Hillis-Steele) and
 // publishes its totals; k_msm_scan_totals: one workgroup scans the tile totals; k_msm_scan_add adds the
-// tile bases, resets the scatter cursors and writes the grand totals off[nbk] / segoff[nbk].
+// tile bases and writes the grand totals off[nbk] / segoff[nbk].
 constexpr uint32_t SCAN_THREADS = 256, SCAN_PER_THREAD = 8, SCAN_TILE = SCAN_THREADS * SCAN_PER_THREAD;
 
 template <class C>
@@ -235,9 +235,9 @@ template <class C>
 __global__ void
 k_msm_scan_add(uint32_t nbk, uint32_t ntiles, const uint32_t *__restrict__ tile_a,
                                       const uint32_t *__restrict__ tile_b, uint32_t *__restrict__ off,
-                                      uint32_t *__restrict__ segoff, uint32_t *__restrict__ cursor) {
+                                      uint32_t *__restrict__ segoff) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < nbk) { const uint32_t tl = b / SCAN_TILE; off[b] += tile_a[tl]; segoff[b] += tile_b[tl]; cursor[b] = 0; }
+    if (b < nbk) { const uint32_t tl = b / SCAN_TILE; off[b] += tile_a[tl]; segoff[b] += tile_b[tl]; }
     if (b == nbk) { off[nbk] = tile_a[ntiles]; segoff[nbk] = tile_b[ntiles]; }
 }
 
@@ -348,7 +348,6 @@ int MsmWork<C>::alloc(uint32_t n, uint32_t c) {
     ZK_HIP(hipMalloc(&hist, sizeof(uint32_t) * (sh.nb + 1)));
     ZK_HIP(hipMalloc(&off, sizeof(uint32_t) * (sh.nb + 1)));
     ZK_HIP(hipMalloc(&segoff, sizeof(uint32_t) * (sh.nb + 1)));
-    ZK_HIP(hipMalloc(&cursor, sizeof(uint32_t) * (sh.nb + 1)));
     ZK_HIP(hipMalloc(&heavy_list, sizeof(uint32_t) * (sh.max_entries() / ((uint64_t)sh.seg * MSM_HEAVY) + 2)));
     ZK_HIP(hipMalloc(&heavy_count, sizeof(uint32_t)));
     ZK_HIP(hipMalloc(&tile_a, sizeof(uint32_t) * (zk_div_up(sh.nb, SCAN_TILE) + 1)));
@@ -364,7 +363,7 @@ int MsmWork<C>::alloc(uint32_t n, uint32_t c) {
 
 template <class C>
 void MsmWork<C>::release() {
-    void *dev[] = {table, pairs, counts, bin_total, bin_base, hist, off, segoff, cursor, sorted, heavy_list, heavy_count, tile_a, tile_b, segsum, bucket, partial_a, partial_b};
+    void *dev[] = {table, pairs, counts, bin_total, bin_base, hist, off, segoff, sorted, heavy_list, heavy_count, tile_a, tile_b, segsum, bucket, partial_a, partial_b};
     for (void *p : dev) if (p) hipFree(p);
     if (host_result) hipHostFree(host_result);
     if (ev_acc0) hipEventDestroy(ev_acc0);
@@ -398,7 +397,7 @@ int MsmWork<C>::enqueue(const fe *scalars, const uint32_t *gather, uint32_t n, i
         const uint32_t ntiles = zk_div_up(nb, SCAN_TILE);
         ZK_LAUNCH_SYNC(k_msm_scan_local<C>, ntiles, SCAN_THREADS, st, (const uint32_t *)hist, nb, seg, off, segoff, tile_a, tile_b);
         ZK_LAUNCH_SYNC(k_msm_scan_totals<C>, 1, 1024, st, tile_a, tile_b, ntiles);
-        ZK_LAUNCH(k_msm_scan_add<C>, zk_div_up(nb + 1, 256), 256, st, nb, ntiles, (const uint32_t *)tile_a, (const uint32_t *)tile_b, off, segoff, cursor);
+        ZK_LAUNCH(k_msm_scan_add<C>, zk_div_up(nb + 1, 256), 256, st, nb, ntiles, (const uint32_t *)tile_a, (const uint32_t *)tile_b, off, segoff);
     }
     // segment count is only known on the device: launch for the upper bound, threads past segoff[nb] exit.
     const uint64_t max_seg = (uint64_t)n * W / seg + nb + 1;
