@@ -134,25 +134,27 @@ k_sort_partition(const fe *__restrict__ scalars, const uint32_t *__restrict__ ga
     }
 }
 
-// pass 2: one workgroup per coarse bin sorts its region by fine bucket; emits hist[], off[] and sorted[]
+// pass 2: one workgroup per coarse bin sorts its region by fine bucket; emits hist[], off[] and sorted[].
+// 1024 threads per workgroup: the pass is latency-bound (two sweeps over ~60 K pairs), so it wants every wave
+// slot of the CU it runs on.
 template <class C>
-__global__ void __launch_bounds__(SORT_THREADS)
+__global__ void __launch_bounds__(SORT_FINE_THREADS)
 k_sort_fine(const uint2 *__restrict__ pairs, const uint32_t *__restrict__ bin_base, SortShape ss,
             uint32_t *__restrict__ hist, uint32_t *__restrict__ off, uint32_t *__restrict__ sorted) {
-    __shared__ uint32_t cnt[SORT_MAX_FB], cur[SORT_MAX_FB], sh[SORT_THREADS];
-    const uint32_t bin = blockIdx.x, r0 = bin_base[bin], r1 = bin_base[bin + 1], t = threadIdx.x;
+    __shared__ uint32_t cnt[SORT_MAX_FB], cur[SORT_MAX_FB], sh[SORT_FINE_THREADS];
+    const uint32_t bin = blockIdx.x, r0 = bin_base[bin], r1 = bin_base[bin + 1], t = threadIdx.x, T = blockDim.x;
     const uint32_t fmask = ss.fb - 1;
-    for (uint32_t k = t; k < ss.fb; k += blockDim.x) cnt[k] = 0;
+    for (uint32_t k = t; k < ss.fb; k += T) cnt[k] = 0;
     __syncthreads();
-    for (uint32_t e = r0 + t; e < r1; e += blockDim.x) atomicAdd(&cnt[pairs[e].y & fmask], 1u);
+    for (uint32_t e = r0 + t; e < r1; e += T) atomicAdd(&cnt[pairs[e].y & fmask], 1u);
     __syncthreads();
     // exclusive scan of cnt[0..fb): thread-serial runs + Hillis-Steele over the run sums
-    const uint32_t per = (ss.fb + SORT_THREADS - 1) / SORT_THREADS, k0 = t * per, k1 = (k0 + per < ss.fb) ? k0 + per : ss.fb;
+    const uint32_t per = (ss.fb + T - 1) / T, k0 = t * per, k1 = (k0 + per < ss.fb) ? k0 + per : ss.fb;
     uint32_t sum = 0;
     for (uint32_t k = k0; k < k1; k++) sum += cnt[k];
     sh[t] = sum;
     __syncthreads();
-    for (uint32_t d = 1; d < SORT_THREADS; d <<= 1) {
+    for (uint32_t d = 1; d < T; d <<= 1) {
         uint32_t v = (t >= d) ? sh[t - d] : 0;
         __syncthreads();
         sh[t] += v;
@@ -165,7 +167,7 @@ k_sort_fine(const uint2 *__restrict__ pairs, const uint32_t *__restrict__ bin_ba
         ex += cnt[k];
     }
     __syncthreads();
-    for (uint32_t e = r0 + t; e < r1; e += blockDim.x) {
+    for (uint32_t e = r0 + t; e < r1; e += T) {
         const uint2 pr = pairs[e];
         sorted[atomicAdd(&cur[pr.y & fmask], 1u)] = pr.x;
     }
@@ -392,7 +394,7 @@ int MsmWork<C>::enqueue(const fe *scalars, const uint32_t *gather, uint32_t n, i
     ZK_LAUNCH_SYNC(k_sort_binscan<C>, 1, SORT_THREADS, st, (const uint32_t *)bin_total, sq.cb, bin_base);
     ZK_LAUNCH_SYNC(k_sort_partition<C>, sq.groups, SORT_THREADS, st, scalars, gather, n, canonical, c, W, sq,
                    (const uint32_t *)counts, (const uint32_t *)bin_base, pairs);
-    ZK_LAUNCH_SYNC(k_sort_fine<C>, sq.cb, SORT_THREADS, st, (const uint2 *)pairs, (const uint32_t *)bin_base, sq, hist, off, sorted);
+    ZK_LAUNCH_SYNC(k_sort_fine<C>, sq.cb, SORT_FINE_THREADS, st, (const uint2 *)pairs, (const uint32_t *)bin_base, sq, hist, off, sorted);
     {   // segments per bucket (and the same off[] again) from the histogram
         const uint32_t ntiles = zk_div_up(nb, SCAN_TILE);
         ZK_LAUNCH_SYNC(k_msm_scan_local<C>, ntiles, SCAN_THREADS, st, (const uint32_t *)hist, nb, seg, off, segoff, tile_a, tile_b);
