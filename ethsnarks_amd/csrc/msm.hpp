@@ -45,7 +45,11 @@ constexpr uint32_t MSM_HEAVY_GRID = 256;
 
 // shapes of the two-pass bucket sort (msm_impl.hpp)
 constexpr uint32_t SORT_THREADS = 256;
+#ifdef ZK_EMUL
+constexpr uint32_t SORT_FINE_THREADS = 64;      // the emulator runs one fiber per GPU thread
+#else
 constexpr uint32_t SORT_FINE_THREADS = 1024;
+#endif
 constexpr uint32_t SORT_MAX_CB = 256;          // coarse bins
 constexpr uint32_t SORT_MAX_FB = 4096;         // fine buckets per coarse bin held in LDS (c <= 20)
 
