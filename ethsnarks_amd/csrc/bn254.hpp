@@ -222,6 +222,7 @@ struct Field {
         t[I - 8] = (uint32_t)lo;
         lo = (lo >> 32) | ((uint64_t)hi << 32); hi = 0;
     }
+    template <bool REDUCE>
     static __device__ __forceinline__ fe mul_fips(const fe &a, const fe &b) {
         uint64_t lo = 0; uint32_t hi = 0;
         uint32_t m[8], t[8];
@@ -233,13 +234,48 @@ struct Field {
         fe r;
 #pragma unroll
         for (int i = 0; i < 8; i++) r.l[i] = t[i];
-        return reduce_once(r);                             // a, b < p  =>  result < 2p < 2^255
+        if constexpr (REDUCE) return reduce_once(r);
+        else return r;                                     // a, b < 2p  =>  result < 2p (p < 2^254): see "loose domain" below
     }
-    static __device__ __forceinline__ fe mul(const fe &a, const fe &b) { return mul_fips(a, b); }
+    static __device__ __forceinline__ fe mul(const fe &a, const fe &b) { return mul_fips<true>(a, b); }
 #else
     static ZK_HD fe mul(const fe &a, const fe &b) { return mul_cios(a, b); }
 #endif
     static ZK_HD fe sqr(const fe &a) { return mul(a, a); }
+
+    // ---- "loose" domain [0, 2p): what the curve formulas compute in on the device.  With p < 2^254 = R/4 the
+    // Montgomery product of two values < 2p is again < 2p WITHOUT the final conditional subtraction
+    // ((4p^2 + Rp)/R < 2p), sums stay below 4p < 2^256, so only add/sub fold back (by 2p).  Zero has two
+    // representatives (0 and p).  Strict operations accept loose inputs where noted (mul does; add/sub do not).
+    // Host code and the CPU emulation map the loose names onto the strict operations (a subset of the domain).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZK_NO_ASM)
+    static __device__ __forceinline__ fe lmul(const fe &a, const fe &b) { return mul_fips<false>(a, b); }
+    static __device__ __forceinline__ fe ladd(const fe &a, const fe &b) {
+        fe s; fips::add8(s.l, a.l, b.l);
+        if constexpr (P::is_fq) fips::reduce8_fq2(s.l); else fips::reduce8_fr2(s.l);
+        return s;
+    }
+    static __device__ __forceinline__ fe lsub(const fe &a, const fe &b) {
+        fe d; uint32_t mask = fips::sub8(d.l, a.l, b.l);
+        if constexpr (P::is_fq) fips::addp_masked8_fq2(d.l, mask); else fips::addp_masked8_fr2(d.l, mask);
+        return d;
+    }
+    static __device__ __forceinline__ bool lis_zero(const fe &a) {
+        uint32_t z = 0, e = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { z |= a.l[i]; e |= a.l[i] ^ P::p(i); }
+        return z == 0 || e == 0;
+    }
+#else
+    static ZK_HD fe lmul(const fe &a, const fe &b) { return mul(a, b); }
+    static ZK_HD fe ladd(const fe &a, const fe &b) { return add(a, b); }
+    static ZK_HD fe lsub(const fe &a, const fe &b) { return sub(a, b); }
+    static ZK_HD bool lis_zero(const fe &a) { return is_zero(a); }
+#endif
+    static ZK_HD fe lsqr(const fe &a) { return lmul(a, a); }
+    static ZK_HD fe ldbl(const fe &a) { return ladd(a, a); }
+    static ZK_HD fe lneg(const fe &a) { return lsub(zero(), a); }
+    static ZK_HD fe canon(const fe &a) { return reduce_once(a); }       // loose -> [0, p)
 
     static ZK_HD fe to_mont(const fe &a) { fe r2; for (int i = 0; i < 8; i++) r2.l[i] = P::r2(i); return mul(a, r2); }
     static ZK_HD fe from_mont(const fe &a) { fe o = zero(); o.l[0] = 1; return mul(a, o); }
@@ -292,6 +328,22 @@ struct Fq2 {
         fe p = Fq::mul(a.c0, a.c1);
         fe2 r; r.c0 = Fq::mul(Fq::add(a.c0, a.c1), Fq::sub(a.c0, a.c1)); r.c1 = Fq::add(p, p); return r;
     }
+    // loose-domain forms (see Field): componentwise
+    static ZK_HD bool lis_zero(const fe2 &a) { return Fq::lis_zero(a.c0) && Fq::lis_zero(a.c1); }
+    static ZK_HD fe2 ladd(const fe2 &a, const fe2 &b) { fe2 r; r.c0 = Fq::ladd(a.c0, b.c0); r.c1 = Fq::ladd(a.c1, b.c1); return r; }
+    static ZK_HD fe2 lsub(const fe2 &a, const fe2 &b) { fe2 r; r.c0 = Fq::lsub(a.c0, b.c0); r.c1 = Fq::lsub(a.c1, b.c1); return r; }
+    static ZK_HD fe2 lneg(const fe2 &a) { fe2 r; r.c0 = Fq::lneg(a.c0); r.c1 = Fq::lneg(a.c1); return r; }
+    static ZK_HD fe2 ldbl(const fe2 &a) { return ladd(a, a); }
+    static ZK_HD fe2 lmul(const fe2 &a, const fe2 &b) {
+        fe v0 = Fq::lmul(a.c0, b.c0), v1 = Fq::lmul(a.c1, b.c1);
+        fe s = Fq::lmul(Fq::ladd(a.c0, a.c1), Fq::ladd(b.c0, b.c1));
+        fe2 r; r.c0 = Fq::lsub(v0, v1); r.c1 = Fq::lsub(Fq::lsub(s, v0), v1); return r;
+    }
+    static ZK_HD fe2 lsqr(const fe2 &a) {
+        fe p = Fq::lmul(a.c0, a.c1);
+        fe2 r; r.c0 = Fq::lmul(Fq::ladd(a.c0, a.c1), Fq::lsub(a.c0, a.c1)); r.c1 = Fq::ladd(p, p); return r;
+    }
+    static ZK_HD fe2 canon(const fe2 &a) { fe2 r; r.c0 = Fq::canon(a.c0); r.c1 = Fq::canon(a.c1); return r; }
     static ZK_HD fe2 inv(const fe2 &a) {
         fe n = Fq::inv(Fq::add(Fq::sqr(a.c0), Fq::sqr(a.c1)));
         fe2 r; r.c0 = Fq::mul(a.c0, n); r.c1 = Fq::neg(Fq::mul(a.c1, n)); return r;
@@ -307,72 +359,72 @@ struct Curve {
     struct alignas(16) Affine { E x, y; };
     struct alignas(16) XYZZ { E X, Y, ZZ, ZZZ; };
 
-    static ZK_HD bool is_inf(const Affine &p) { return F::is_zero(p.x) && F::is_zero(p.y); }
-    static ZK_HD bool is_inf(const XYZZ &p) { return F::is_zero(p.ZZ); }
+    static ZK_HD bool is_inf(const Affine &p) { return F::lis_zero(p.x) && F::lis_zero(p.y); }
+    static ZK_HD bool is_inf(const XYZZ &p) { return F::lis_zero(p.ZZ); }
     static ZK_HD XYZZ infinity() { XYZZ r; r.X = F::zero(); r.Y = F::zero(); r.ZZ = F::zero(); r.ZZZ = F::zero(); return r; }
     static ZK_HD Affine aff_infinity() { Affine r; r.x = F::zero(); r.y = F::zero(); return r; }
     static ZK_HD XYZZ from_affine(const Affine &p) {
         if (is_inf(p)) return infinity();
         XYZZ r; r.X = p.x; r.Y = p.y; r.ZZ = F::one(); r.ZZZ = F::one(); return r;
     }
-    static ZK_HD Affine neg(const Affine &p) { Affine r; r.x = p.x; r.y = F::neg(p.y); return r; }
-    static ZK_HD XYZZ neg(const XYZZ &p) { XYZZ r = p; r.Y = F::neg(p.Y); return r; }
+    static ZK_HD Affine neg(const Affine &p) { Affine r; r.x = p.x; r.y = F::lneg(p.y); return r; }
+    static ZK_HD XYZZ neg(const XYZZ &p) { XYZZ r = p; r.Y = F::lneg(p.Y); return r; }
 
     // 2 * affine (mdbl-2008-s-1)
     static ZK_HD XYZZ dbl_affine(const Affine &p) {
         if (is_inf(p)) return infinity();
-        E U = F::dbl(p.y), V = F::sqr(U), W = F::mul(U, V), S = F::mul(p.x, V);
-        E xx = F::sqr(p.x), M = F::add(F::dbl(xx), xx);
+        E U = F::ldbl(p.y), V = F::lsqr(U), W = F::lmul(U, V), S = F::lmul(p.x, V);
+        E xx = F::lsqr(p.x), M = F::ladd(F::ldbl(xx), xx);
         XYZZ r;
-        r.X = F::sub(F::sqr(M), F::dbl(S));
-        r.Y = F::sub(F::mul(M, F::sub(S, r.X)), F::mul(W, p.y));
+        r.X = F::lsub(F::lsqr(M), F::ldbl(S));
+        r.Y = F::lsub(F::lmul(M, F::lsub(S, r.X)), F::lmul(W, p.y));
         r.ZZ = V; r.ZZZ = W;
         return r;
     }
     // dbl-2008-s-1
     static ZK_HD XYZZ dbl(const XYZZ &p) {
         if (is_inf(p)) return p;
-        E U = F::dbl(p.Y), V = F::sqr(U), W = F::mul(U, V), S = F::mul(p.X, V);
-        E xx = F::sqr(p.X), M = F::add(F::dbl(xx), xx);
+        E U = F::ldbl(p.Y), V = F::lsqr(U), W = F::lmul(U, V), S = F::lmul(p.X, V);
+        E xx = F::lsqr(p.X), M = F::ladd(F::ldbl(xx), xx);
         XYZZ r;
-        r.X = F::sub(F::sqr(M), F::dbl(S));
-        r.Y = F::sub(F::mul(M, F::sub(S, r.X)), F::mul(W, p.Y));
-        r.ZZ = F::mul(V, p.ZZ); r.ZZZ = F::mul(W, p.ZZZ);
+        r.X = F::lsub(F::lsqr(M), F::ldbl(S));
+        r.Y = F::lsub(F::lmul(M, F::lsub(S, r.X)), F::lmul(W, p.Y));
+        r.ZZ = F::lmul(V, p.ZZ); r.ZZZ = F::lmul(W, p.ZZZ);
         return r;
     }
     // p + q, q affine (madd-2008-s); all exceptional cases handled -- bit-exactness needs them
     static ZK_HD XYZZ madd(const XYZZ &p, const Affine &q) {
         if (is_inf(q)) return p;
         if (is_inf(p)) { XYZZ r; r.X = q.x; r.Y = q.y; r.ZZ = F::one(); r.ZZZ = F::one(); return r; }
-        E U2 = F::mul(q.x, p.ZZ), S2 = F::mul(q.y, p.ZZZ);
-        E Pd = F::sub(U2, p.X), R = F::sub(S2, p.Y);
-        if (F::is_zero(Pd)) {
-            if (F::is_zero(R)) return dbl_affine(q);
+        E U2 = F::lmul(q.x, p.ZZ), S2 = F::lmul(q.y, p.ZZZ);
+        E Pd = F::lsub(U2, p.X), R = F::lsub(S2, p.Y);
+        if (F::lis_zero(Pd)) {
+            if (F::lis_zero(R)) return dbl_affine(q);
             return infinity();
         }
-        E PP = F::sqr(Pd), PPP = F::mul(Pd, PP), Q = F::mul(p.X, PP);
+        E PP = F::lsqr(Pd), PPP = F::lmul(Pd, PP), Q = F::lmul(p.X, PP);
         XYZZ r;
-        r.X = F::sub(F::sub(F::sqr(R), PPP), F::dbl(Q));
-        r.Y = F::sub(F::mul(R, F::sub(Q, r.X)), F::mul(p.Y, PPP));
-        r.ZZ = F::mul(p.ZZ, PP); r.ZZZ = F::mul(p.ZZZ, PPP);
+        r.X = F::lsub(F::lsub(F::lsqr(R), PPP), F::ldbl(Q));
+        r.Y = F::lsub(F::lmul(R, F::lsub(Q, r.X)), F::lmul(p.Y, PPP));
+        r.ZZ = F::lmul(p.ZZ, PP); r.ZZZ = F::lmul(p.ZZZ, PPP);
         return r;
     }
     // p + q (add-2008-s)
     static ZK_HD XYZZ add(const XYZZ &p, const XYZZ &q) {
         if (is_inf(p)) return q;
         if (is_inf(q)) return p;
-        E U1 = F::mul(p.X, q.ZZ), U2 = F::mul(q.X, p.ZZ);
-        E S1 = F::mul(p.Y, q.ZZZ), S2 = F::mul(q.Y, p.ZZZ);
-        E Pd = F::sub(U2, U1), R = F::sub(S2, S1);
-        if (F::is_zero(Pd)) {
-            if (F::is_zero(R)) return dbl(p);
+        E U1 = F::lmul(p.X, q.ZZ), U2 = F::lmul(q.X, p.ZZ);
+        E S1 = F::lmul(p.Y, q.ZZZ), S2 = F::lmul(q.Y, p.ZZZ);
+        E Pd = F::lsub(U2, U1), R = F::lsub(S2, S1);
+        if (F::lis_zero(Pd)) {
+            if (F::lis_zero(R)) return dbl(p);
             return infinity();
         }
-        E PP = F::sqr(Pd), PPP = F::mul(Pd, PP), Q = F::mul(U1, PP);
+        E PP = F::lsqr(Pd), PPP = F::lmul(Pd, PP), Q = F::lmul(U1, PP);
         XYZZ r;
-        r.X = F::sub(F::sub(F::sqr(R), PPP), F::dbl(Q));
-        r.Y = F::sub(F::mul(R, F::sub(Q, r.X)), F::mul(S1, PPP));
-        r.ZZ = F::mul(F::mul(p.ZZ, q.ZZ), PP); r.ZZZ = F::mul(F::mul(p.ZZZ, q.ZZZ), PPP);
+        r.X = F::lsub(F::lsub(F::lsqr(R), PPP), F::ldbl(Q));
+        r.Y = F::lsub(F::lmul(R, F::lsub(Q, r.X)), F::lmul(S1, PPP));
+        r.ZZ = F::lmul(F::lmul(p.ZZ, q.ZZ), PP); r.ZZZ = F::lmul(F::lmul(p.ZZZ, q.ZZZ), PPP);
         return r;
     }
     // k * p for a small non-negative integer k (bucket-offset weighting), MSB-first double-and-add
@@ -385,11 +437,16 @@ struct Curve {
         }
         return acc;
     }
+    // The formulas above run in the loose domain [0, 2p) of the field (no-op on the host).  to_affine normalises
+    // its input and computes strictly, so affine outputs (tables, keys) are canonical; canon() normalises an XYZZ
+    // point that leaves the device as it is (MSM results).
+    static ZK_HD XYZZ canon(const XYZZ &p) { XYZZ r; r.X = F::canon(p.X); r.Y = F::canon(p.Y); r.ZZ = F::canon(p.ZZ); r.ZZZ = F::canon(p.ZZZ); return r; }
     static ZK_HD Affine to_affine(const XYZZ &p) {      // one inversion: 1/(ZZ*ZZZ)
         if (is_inf(p)) return aff_infinity();
-        E i = F::inv(F::mul(p.ZZ, p.ZZZ));
-        E izz = F::mul(i, p.ZZZ), izzz = F::mul(i, p.ZZ);
-        Affine r; r.x = F::mul(p.X, izz); r.y = F::mul(p.Y, izzz); return r;
+        const XYZZ c = canon(p);                        // strict arithmetic from here on
+        E i = F::inv(F::mul(c.ZZ, c.ZZZ));
+        E izz = F::mul(i, c.ZZZ), izzz = F::mul(i, c.ZZ);
+        Affine r; r.x = F::mul(c.X, izz); r.y = F::mul(c.Y, izzz); return r;
     }
 };
 

@@ -108,7 +108,7 @@ struct MsmWork {
     // enqueue the MSM: sort + accumulation (machine-filling) on `st`, the low-parallelism bucket reduction on
     // `st_tail` (may equal st); the result lands in host_result after st_tail drains
     int enqueue(const fe *scalars, const uint32_t *gather, uint32_t n, int canonical, hipStream_t st, hipStream_t st_tail);
-    typename C::XYZZ finish() const { return *host_result; }
+    typename C::XYZZ finish() const { return C::canon(*host_result); }   // device values are loose ([0, 2p)): normalise once
 };
 
 }  // namespace zk
