@@ -187,7 +187,9 @@ def main():
                                  "each base is read through its W window multiples (msm.hpp), trading HBM bytes for 16x fewer bucket reductions"},
             "valu": {"kernel": "k_msm_accumulate<G2>", "unit": "G Fq-mul/s", "achieved": round(fq_muls / (kern_ms * 1e-3) / 1e9, 3) if kern_ms > 0 else 0.0,
                      "peak": round(MAD_LANE_OPS_PER_CLK_CU * 256 * 2.4 / FQ_MUL_MADS, 1),
-                     "peak_basis": "measured v_mad_u64_u32 issue rate x 256 CU x 2.4 GHz / 136 mads per Montgomery product"},
+                     "peak_basis": "measured v_mad_u64_u32 issue rate x 256 CU x 2.4 GHz / 136 mads per Montgomery product",
+                     "issue_slot_bound": round(256 * 128 * 2.4 / (136 * 2.47 + 155), 1),
+                     "issue_slot_basis": "all VALU issue slots at 2.4 GHz spent on the product's own mix: 136 multiplies at 2.47 slots + 155 single-slot instructions"},
             "proof_hbm": {"algorithmic_bytes_per_proof": bytes_per_proof,
                           "achieved_GBps": round(bytes_per_proof * value / 1e9, 3),
                           "frac_of_peak": round(bytes_per_proof * value / 1e9 / (world * HBM_PEAK_GBPS), 6)},
