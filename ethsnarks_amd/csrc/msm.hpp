@@ -92,6 +92,7 @@ struct MsmWork {
     SortShape ss;
     typename C::Affine *table = nullptr;        // [W][table_n] window multiples of the bases, resident for the context's life
     uint32_t table_n = 0;
+    bool owns_table = true;                     // false: the table belongs to a DeviceTables entry shared by several contexts
     uint2 *pairs = nullptr;                     // pass-1 output of the bucket sort: (payload, bucket)
     uint32_t *counts = nullptr, *bin_total = nullptr, *bin_base = nullptr;
     uint32_t *hist = nullptr, *off = nullptr, *segoff = nullptr, *sorted = nullptr;
@@ -101,7 +102,8 @@ struct MsmWork {
     hipEvent_t ev_acc0 = nullptr, ev_acc1 = nullptr;   // bracket k_msm_accumulate (the dominant kernel) on its stream
     float accumulate_ms() const { float ms = 0; if (ev_acc0 && ev_acc1) hipEventElapsedTime(&ms, ev_acc0, ev_acc1); return ms; }
 
-    int alloc(uint32_t n, uint32_t c);
+    // shared_table: an already expanded table of exactly these n bases (same c) to borrow; nullptr: allocate one
+    int alloc(uint32_t n, uint32_t c, typename C::Affine *shared_table = nullptr);
     void release();
     // table <- window multiples of d_bases[0..n) (device pointer); once per context
     int precompute(const typename C::Affine *d_bases, uint32_t n, hipStream_t st);

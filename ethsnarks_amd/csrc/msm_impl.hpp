@@ -337,10 +337,11 @@ k_msm_tree_sum(const typename C::XYZZ *__restrict__ in, uint32_t count, typename
 
 // -------------------------------------------------------------------------------------------------
 template <class C>
-int MsmWork<C>::alloc(uint32_t n, uint32_t c) {
+int MsmWork<C>::alloc(uint32_t n, uint32_t c, typename C::Affine *shared_table) {
     sh.set(n ? n : 1, c);
     const uint32_t K = sh.nb < MSM_GROUP ? sh.nb : MSM_GROUP, groups = sh.nb / K;
-    ZK_HIP(hipMalloc(&table, sizeof(typename C::Affine) * sh.max_entries()));
+    if (shared_table) { table = shared_table; owns_table = false; table_n = n; }
+    else ZK_HIP(hipMalloc(&table, sizeof(typename C::Affine) * sh.max_entries()));
     ss.set(sh.n, sh.nb);
     ZK_HIP(hipMalloc(&pairs, sizeof(uint2) * sh.max_entries()));
     ZK_HIP(hipMalloc(&counts, sizeof(uint32_t) * ((size_t)ss.cb * ss.groups + 1)));
@@ -365,6 +366,7 @@ int MsmWork<C>::alloc(uint32_t n, uint32_t c) {
 
 template <class C>
 void MsmWork<C>::release() {
+    if (!owns_table) table = nullptr;
     void *dev[] = {table, pairs, counts, bin_total, bin_base, hist, off, segoff, sorted, heavy_list, heavy_count, tile_a, tile_b, segsum, bucket, partial_a, partial_b};
     for (void *p : dev) if (p) hipFree(p);
     if (host_result) hipHostFree(host_result);

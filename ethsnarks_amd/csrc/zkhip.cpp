@@ -4,6 +4,8 @@
 //   pk_nozk stream operators       ...tcc:108-143
 //   proof_to_json                  src/export.cpp:20-121
 // around the kernels of ntt.hpp / msm.hpp.  No CPU compute path exists in this library.
+#include <atomic>
+#include <mutex>
 #include <string>
 #include <vector>
 #include <chrono>
@@ -68,7 +70,9 @@ static int use_device(int device) {
 }
 
 // ================================================================ proving key (host)
+static std::atomic<uint64_t> g_pk_ids{1};
 struct zk_pk {
+    const uint64_t id = g_pk_ids.fetch_add(1);          // identity of the key for the device-table cache below
     G1::Affine alpha_g1, beta_g1, delta_g1;
     G2::Affine beta_g2, delta_g2;
     uint32_t a_domain = 0, b_domain = 0;
@@ -289,8 +293,47 @@ Range shard_range(uint32_t n, uint32_t rank, uint32_t count) {
 }
 }  // namespace
 
+
+// ---- window-multiple tables of one key shard on one device, shared by every context created for it
+// (the reference shares one ProvingKeyT among ProverContexts the same way, hpp:279-291): 5 GB at n = 2^20.
+namespace {
+struct DeviceTables {
+    uint64_t pk_id = 0; int device = 0; uint32_t rank = 0, count = 1, cbits = 0;
+    G1::Affine *tA = nullptr, *tH = nullptr, *tL = nullptr; G2::Affine *tB = nullptr;
+    uint32_t *dA_idx = nullptr, *dB_idx = nullptr;
+    int refs = 0;
+};
+std::mutex g_tables_mu;
+std::vector<DeviceTables *> g_tables;
+
+template <class C>
+int build_table(typename C::Affine **out, const typename C::Affine *host_bases, uint32_t n, uint32_t cbits) {
+    MsmWork<C> tmp;                                      // only to own the expansion; its scratch is released again
+    typename C::Affine *d_bases = nullptr;
+    int rc = tmp.alloc(n, cbits);
+    if (rc == ZK_OK) rc = dev_upload(&d_bases, host_bases, n);
+    if (rc == ZK_OK) rc = tmp.precompute(d_bases, n, nullptr);
+    if (rc == ZK_OK && hipDeviceSynchronize() != hipSuccess) rc = fail(ZK_ERR_HIP, "k_msm_precompute failed");
+    if (d_bases) hipFree(d_bases);
+    if (rc == ZK_OK) { *out = tmp.table; tmp.owns_table = false; }      // keep the table, drop the rest
+    tmp.release();
+    return rc;
+}
+void tables_release(DeviceTables *t) {
+    if (!t) return;
+    std::lock_guard<std::mutex> lk(g_tables_mu);
+    if (--t->refs > 0) return;
+    hipSetDevice(t->device);
+    void *dev[] = {t->tA, t->tH, t->tL, t->tB, t->dA_idx, t->dB_idx};
+    for (void *p : dev) if (p) hipFree(p);
+    for (size_t i = 0; i < g_tables.size(); i++) if (g_tables[i] == t) { g_tables.erase(g_tables.begin() + i); break; }
+    delete t;
+}
+}  // namespace
+
 struct zk_ctx {
     int device = 0;
+    DeviceTables *tables = nullptr;
     bool serial = false;
     bool in_flight = false;
     uint32_t nC = 0, nIn = 0, V = 0, m = 0, logm = 0;
@@ -310,13 +353,14 @@ struct zk_ctx {
                ev_l0 = nullptr, ev_l1 = nullptr, ev_h1 = nullptr, ev_h0 = nullptr;
     ~zk_ctx() {
         hipSetDevice(device);
-        void *dev[] = {dA_idx, dB_idx, d_w, d_a, d_b, d_c, d_t};
+        void *dev[] = {d_w, d_a, d_b, d_c, d_t};
         for (void *p : dev) if (p) hipFree(p);
         if (h_w) hipHostFree(h_w);
         if (h_tail) hipHostFree(h_tail);
         cA.release(); cB.release(); cC.release();
         ntt_tables_free(tab);
         mA.release(); mH.release(); mL.release(); mB.release();
+        tables_release(tables);
         if (serial) s_a = s_b = s_l = nullptr;
         hipStream_t ss[] = {s_main, s_a, s_b, s_l};
         for (auto s : ss) if (s) hipStreamDestroy(s);
@@ -339,29 +383,37 @@ static int ctx_build(zk_ctx *c, const zk_pk *pk, const zk_csr *A, const zk_csr *
     c->rB = shard_range((uint32_t)pk->b_val.size(), r, G);
     c->rH = shard_range(m - 1, r, G);
     c->rL = shard_range(V - nIn, r, G);
-    ZK_TRY(dev_upload(&c->dA_idx, pk->a_idx.data() + c->rA.lo, c->rA.n()));
-    ZK_TRY(dev_upload(&c->dB_idx, pk->b_idx.data() + c->rB.lo, c->rB.n()));
-    // bases -> window-multiple tables (msm.hpp); the raw affine arrays are only staging
-    {
-        G1::Affine *d1 = nullptr; G2::Affine *d2 = nullptr;
-        auto build1 = [&](MsmWork<G1> &w, const G1::Affine *src, uint32_t n) -> int {
-            ZK_TRY(w.alloc(n, c->cfg.multi_exp_c));
-            ZK_TRY(dev_upload(&d1, src, n));
-            int rc = w.precompute(d1, n, nullptr);
-            if (rc == ZK_OK && hipDeviceSynchronize() != hipSuccess) rc = fail(ZK_ERR_HIP, "k_msm_precompute failed");
-            hipFree(d1); d1 = nullptr;
-            return rc;
-        };
-        ZK_TRY(build1(c->mA, pk->a_val.data() + c->rA.lo, c->rA.n()));
-        ZK_TRY(build1(c->mH, pk->H.data() + c->rH.lo, c->rH.n()));
-        ZK_TRY(build1(c->mL, pk->L.data() + c->rL.lo, c->rL.n()));
-        ZK_TRY(c->mB.alloc(c->rB.n(), c->cfg.multi_exp_c));
-        ZK_TRY(dev_upload(&d2, pk->b_val.data() + c->rB.lo, c->rB.n()));
-        int rc = c->mB.precompute(d2, c->rB.n(), nullptr);
-        if (rc == ZK_OK && hipDeviceSynchronize() != hipSuccess) rc = fail(ZK_ERR_HIP, "k_msm_precompute failed");
-        hipFree(d2);
-        ZK_TRY(rc);
+    {   // find or build the shared device tables of this (key, device, shard, window) combination
+        std::lock_guard<std::mutex> lk(g_tables_mu);
+        DeviceTables *t = nullptr;
+        for (DeviceTables *e : g_tables)
+            if (e->pk_id == pk->id && e->device == c->device && e->rank == r && e->count == G && e->cbits == c->cfg.multi_exp_c) { t = e; break; }
+        if (!t) {
+            t = new (std::nothrow) DeviceTables();
+            if (!t) return ZK_ERR_NOMEM;
+            t->pk_id = pk->id; t->device = c->device; t->rank = r; t->count = G; t->cbits = c->cfg.multi_exp_c;
+            int rc = dev_upload(&t->dA_idx, pk->a_idx.data() + c->rA.lo, c->rA.n());
+            if (rc == ZK_OK) rc = dev_upload(&t->dB_idx, pk->b_idx.data() + c->rB.lo, c->rB.n());
+            if (rc == ZK_OK) rc = build_table<G1>(&t->tA, pk->a_val.data() + c->rA.lo, c->rA.n(), t->cbits);
+            if (rc == ZK_OK) rc = build_table<G1>(&t->tH, pk->H.data() + c->rH.lo, c->rH.n(), t->cbits);
+            if (rc == ZK_OK) rc = build_table<G1>(&t->tL, pk->L.data() + c->rL.lo, c->rL.n(), t->cbits);
+            if (rc == ZK_OK) rc = build_table<G2>(&t->tB, pk->b_val.data() + c->rB.lo, c->rB.n(), t->cbits);
+            if (rc != ZK_OK) {
+                void *dev[] = {t->tA, t->tH, t->tL, t->tB, t->dA_idx, t->dB_idx};
+                for (void *p : dev) if (p) hipFree(p);
+                delete t;
+                return rc;
+            }
+            g_tables.push_back(t);
+        }
+        t->refs++;
+        c->tables = t;
     }
+    c->dA_idx = c->tables->dA_idx; c->dB_idx = c->tables->dB_idx;
+    ZK_TRY(c->mA.alloc(c->rA.n(), c->cfg.multi_exp_c, c->tables->tA));
+    ZK_TRY(c->mH.alloc(c->rH.n(), c->cfg.multi_exp_c, c->tables->tH));
+    ZK_TRY(c->mL.alloc(c->rL.n(), c->cfg.multi_exp_c, c->tables->tL));
+    ZK_TRY(c->mB.alloc(c->rB.n(), c->cfg.multi_exp_c, c->tables->tB));
     ZK_TRY(c->cA.upload(A, V)); ZK_TRY(c->cB.upload(B, V)); ZK_TRY(c->cC.upload(C, V));
     ZK_HIP(hipMalloc(&c->d_w, 32 * (size_t)(V + 1)));
     ZK_HIP(hipMalloc(&c->d_a, 32 * (size_t)m)); ZK_HIP(hipMalloc(&c->d_b, 32 * (size_t)m));
