@@ -50,3 +50,22 @@ def test_missing_library_is_an_import_error(tmp_path):
     prover._lib = None; prover._lib_path_loaded = None
     with pytest.raises(ImportError):
         prover.load_library(str(tmp_path / "libzkhip.so"))
+
+
+@pytest.mark.skipif(not os.path.exists(LIB), reason="libzkhip.so not built (run __graft_entry__.build())")
+def test_plain_c_client_links_and_verifies(tmp_path):
+    """include/zkhip.h is a C header: a C99 program links libzkhip.so and runs the host-side verifier on the
+    reference's static triple (no GPU involved)."""
+    import json, subprocess
+    exe = str(tmp_path / "c_abi_client")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c_abi_client.c"), "-o", exe, LIB,
+                           "-Wl,-rpath," + os.path.dirname(LIB), "-Wl,-rpath,/opt/rocm/lib"])
+    d = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_static_triple.json")))
+    vk, pf, bad = tmp_path / "vk.json", tmp_path / "proof.json", tmp_path / "bad.json"
+    vk.write_text(json.dumps(d["vk"])); pf.write_text(json.dumps(d["proof"]))
+    bad.write_text(json.dumps(dict(d["proof"], input=[d["proof"]["input"][0], "0x8"])))
+    out = subprocess.run([exe, str(vk), str(pf)], capture_output=True, text=True)
+    assert out.returncode == 0 and "accepted" in out.stdout and "= 1048576" in out.stdout, out.stdout + out.stderr
+    out = subprocess.run([exe, str(vk), str(bad)], capture_output=True, text=True)
+    assert out.returncode == 1 and "rejected" in out.stdout
