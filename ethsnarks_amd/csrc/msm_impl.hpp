@@ -339,6 +339,7 @@ k_msm_tree_sum(const typename C::XYZZ *__restrict__ in, uint32_t count, typename
 template <class C>
 int MsmWork<C>::alloc(uint32_t n, uint32_t c, typename C::Affine *shared_table) {
     sh.set(n ? n : 1, c);
+    if (sh.max_entries() >= (1ull << 31)) return ZK_ERR_ARG;     // entry payload = table index (31 bits) | sign
     const uint32_t K = sh.nb < MSM_GROUP ? sh.nb : MSM_GROUP, groups = sh.nb / K;
     if (shared_table) { table = shared_table; owns_table = false; table_n = n; }
     else ZK_HIP(hipMalloc(&table, sizeof(typename C::Affine) * sh.max_entries()));
