@@ -35,7 +35,8 @@ namespace zk {
 constexpr uint32_t MSM_SEG_MIN = 32;      // entries per accumulation thread (lower bound)
 constexpr uint32_t MSM_SEG_PER_BUCKET = 16;   // target segments per bucket (sets the segment length)
 constexpr uint32_t MSM_HEAVY = 64;        // buckets with more segments than this are reduced by a workgroup
-constexpr uint32_t MSM_GROUP = 8;         // buckets per running-sum thread
+constexpr uint32_t MSM_GROUP = 8;         // buckets per running-sum thread (ZK_MSM_GROUP overrides: tuning aid)
+inline uint32_t msm_group() { if (const char *e = getenv("ZK_MSM_GROUP")) { int v = atoi(e); if (v >= 1 && v <= 1024) return (uint32_t)v; } return MSM_GROUP; }
 constexpr uint32_t MSM_TREE = 256;        // fan-in (= workgroup size) of the final tree sum
 #ifdef ZK_EMUL
 constexpr uint32_t MSM_HEAVY_GRID = 2;    // the emulator spawns a real thread per GPU thread
@@ -60,6 +61,7 @@ struct SortShape {
         fb = nb / cb;
         fine_bits = 0; while ((1u << fine_bits) < fb) fine_bits++;
         per_group = 1024;                                   // 1024 scalars x W windows of LDS-ranked entries per workgroup
+        if (const char *e = getenv("ZK_SORT_PER_GROUP")) { int v = atoi(e); if (v >= 64) per_group = (uint32_t)v; }   // tuning aid
         groups = (n + per_group - 1) / per_group; if (!groups) groups = 1;
     }
 };
@@ -78,6 +80,7 @@ struct MsmShape {
         if (c > 20) c = 20;
         W = 254 / c + 1; nb = 1u << (c - 1);
         seg = MSM_SEG_MIN;
+        if (const char *e = getenv("ZK_SEG_MIN")) { int v = atoi(e); if (v >= 4) seg = (uint32_t)v; }                // tuning aid
         uint32_t spb = MSM_SEG_PER_BUCKET;
         if (const char *e = getenv("ZK_SEG_PER_BUCKET")) { int v = atoi(e); if (v > 0) spb = (uint32_t)v; }   // tuning aid
         while (seg < 4096 && (uint64_t)seg * nb * spb < max_entries()) seg <<= 1;

@@ -340,7 +340,7 @@ template <class C>
 int MsmWork<C>::alloc(uint32_t n, uint32_t c, typename C::Affine *shared_table) {
     sh.set(n ? n : 1, c);
     if (sh.max_entries() >= (1ull << 31)) return ZK_ERR_ARG;     // entry payload = table index (31 bits) | sign
-    const uint32_t K = sh.nb < MSM_GROUP ? sh.nb : MSM_GROUP, groups = sh.nb / K;
+    const uint32_t G0 = msm_group(), K = sh.nb < G0 ? sh.nb : G0, groups = sh.nb / K;
     if (shared_table) { table = shared_table; owns_table = false; table_n = n; }
     else ZK_HIP(hipMalloc(&table, sizeof(typename C::Affine) * sh.max_entries()));
     ss.set(sh.n, sh.nb);
@@ -389,7 +389,7 @@ template <class C>
 int MsmWork<C>::enqueue(const fe *scalars, const uint32_t *gather, uint32_t n, int canonical, hipStream_t st, hipStream_t st_tail) {
     if (n != table_n) return ZK_ERR_ARG;                        // the table stride is the precompute-time n
     const uint32_t c = sh.c, W = sh.W, nb = sh.nb, seg = sh.seg;
-    const uint32_t K = nb < MSM_GROUP ? nb : MSM_GROUP, groups = nb / K;
+    const uint32_t G0 = msm_group(), K = nb < G0 ? nb : G0, groups = nb / K;
     ZK_HIP(hipMemsetAsync(heavy_count, 0, sizeof(uint32_t), st));
     SortShape sq = ss; sq.set(n ? n : 1, nb);                   // same bins; workgroups sized for this call's n
     ZK_LAUNCH_SYNC(k_sort_count<C>, sq.groups, SORT_THREADS, st, scalars, gather, n, canonical, c, W, sq, counts);
