@@ -89,6 +89,15 @@ struct MsmShape {
     uint64_t max_segments() const { return max_entries() / seg + nb + 1; }
 };
 
+// what k_msm_accumulate needs from a finished bucket sort; `remap_src` != 0 means the entries index another
+// MSM's table ([w][remap_src] layout, scalar i) and this MSM covers scalars [remap_offset, remap_offset + n)
+struct SortView {
+    const uint32_t *sorted = nullptr, *off = nullptr, *segoff = nullptr;
+    uint32_t seg = 0, entries_bound = 0;            // entries_bound: upper bound of sorted entries (n_src * W)
+    uint32_t remap_src = 0, remap_offset = 0;
+    const uint32_t *remap_pos = nullptr;            // optional scalar index -> own base index (0xffffffff: absent); else i - remap_offset
+};
+
 template <class C>
 struct MsmWork {
     MsmShape sh;
@@ -105,14 +114,24 @@ struct MsmWork {
     hipEvent_t ev_acc0 = nullptr, ev_acc1 = nullptr;   // bracket k_msm_accumulate (the dominant kernel) on its stream
     float accumulate_ms() const { float ms = 0; if (ev_acc0 && ev_acc1) hipEventElapsedTime(&ms, ev_acc0, ev_acc1); return ms; }
 
-    // shared_table: an already expanded table of exactly these n bases (same c) to borrow; nullptr: allocate one
-    int alloc(uint32_t n, uint32_t c, typename C::Affine *shared_table = nullptr);
+    // shared_table: an already expanded table of exactly these n bases (same c) to borrow; nullptr: allocate one.
+    // sort_like: this MSM will be driven by ANOTHER MsmWork's sort (same scalars: A-, B- and L-query all read the
+    // witness): take that shape (same c, W, buckets, segment length), size the reduction buffers for its entries,
+    // and do not allocate sort buffers of its own.
+    // sort_only: no table and no reduction buffers -- this object only sorts a scalar vector for others.
+    int alloc(uint32_t n, uint32_t c, typename C::Affine *shared_table = nullptr, const MsmShape *sort_like = nullptr, bool sort_only = false);
     void release();
     // table <- window multiples of d_bases[0..n) (device pointer); once per context
     int precompute(const typename C::Affine *d_bases, uint32_t n, hipStream_t st);
     // enqueue the MSM: sort + accumulation (machine-filling) on `st`, the low-parallelism bucket reduction on
     // `st_tail` (may equal st); the result lands in host_result after st_tail drains
     int enqueue(const fe *scalars, const uint32_t *gather, uint32_t n, int canonical, hipStream_t st, hipStream_t st_tail);
+    // the two halves: the bucket sort of this MSM's scalars, and accumulation + reduction driven by a sort view
+    int enqueue_sort(const fe *scalars, const uint32_t *gather, uint32_t n, int canonical, hipStream_t st);
+    int enqueue_reduce(const SortView &v, hipStream_t st, hipStream_t st_tail);
+    SortView view() const { SortView v; v.sorted = sorted; v.off = off; v.segoff = segoff; v.seg = sh.seg; v.entries_bound = (uint32_t)((uint64_t)table_n * sh.W); return v; }
+    // view for an MSM over scalars [offset, offset + n_dst) of THIS sort (its table has stride n_dst)
+    SortView view_for(uint32_t offset, const uint32_t *pos = nullptr) const { SortView v = view(); v.remap_src = table_n; v.remap_offset = offset; v.remap_pos = pos; return v; }
     typename C::XYZZ finish() const { return C::canon(*host_result); }   // device values are loose ([0, 2p)): normalise once
 };
 

@@ -248,6 +248,7 @@ template <class C>
 __global__ void __launch_bounds__(64, C::WAVES_PER_SIMD)
 k_msm_accumulate(const typename C::Affine *__restrict__ table, const uint32_t *__restrict__ sorted,
                  const uint32_t *__restrict__ off, const uint32_t *__restrict__ segoff, uint32_t nb, uint32_t seg,
+                 uint32_t remap_src, uint32_t remap_offset, const uint32_t *__restrict__ remap_pos, uint32_t n_dst,
                  typename C::XYZZ *__restrict__ segsum) {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t nseg = segoff[nb];
@@ -259,8 +260,14 @@ k_msm_accumulate(const typename C::Affine *__restrict__ table, const uint32_t *_
     if (end > off[b + 1]) end = off[b + 1];
     typename C::XYZZ acc = C::infinity();
     for (uint32_t e = begin; e < end; e++) {
-        uint32_t p = sorted[e];
-        typename C::Affine q = table[p & 0x7fffffffu];
+        uint32_t p = sorted[e], idx = p & 0x7fffffffu;
+        if (remap_src) {                                        // entry of another query's sort: (window, scalar) -> own table
+            const uint32_t w = idx / remap_src, i = idx - w * remap_src;
+            const uint32_t k = remap_pos ? remap_pos[i] : i - remap_offset;     // unsigned wrap / 0xffffffff = absent
+            if (k >= n_dst) continue;
+            idx = w * n_dst + k;
+        }
+        typename C::Affine q = table[idx];
         if (p >> 31) q = C::neg(q);
         acc = C::madd(acc, q);
     }
@@ -337,25 +344,29 @@ k_msm_tree_sum(const typename C::XYZZ *__restrict__ in, uint32_t count, typename
 
 // -------------------------------------------------------------------------------------------------
 template <class C>
-int MsmWork<C>::alloc(uint32_t n, uint32_t c, typename C::Affine *shared_table) {
-    sh.set(n ? n : 1, c);
+int MsmWork<C>::alloc(uint32_t n, uint32_t c, typename C::Affine *shared_table, const MsmShape *sort_like, bool sort_only) {
+    if (sort_like) sh = *sort_like; else sh.set(n ? n : 1, c);
     if (sh.max_entries() >= (1ull << 31)) return ZK_ERR_ARG;     // entry payload = table index (31 bits) | sign
     const uint32_t G0 = msm_group(), K = sh.nb < G0 ? sh.nb : G0, groups = sh.nb / K;
-    if (shared_table) { table = shared_table; owns_table = false; table_n = n; }
-    else ZK_HIP(hipMalloc(&table, sizeof(typename C::Affine) * sh.max_entries()));
+    if (sort_only) { owns_table = false; table_n = n; }
+    else if (shared_table) { table = shared_table; owns_table = false; table_n = n; }
+    else ZK_HIP(hipMalloc(&table, sizeof(typename C::Affine) * (size_t)(n ? n : 1) * sh.W));
     ss.set(sh.n, sh.nb);
-    ZK_HIP(hipMalloc(&pairs, sizeof(uint2) * sh.max_entries()));
-    ZK_HIP(hipMalloc(&counts, sizeof(uint32_t) * ((size_t)ss.cb * ss.groups + 1)));
-    ZK_HIP(hipMalloc(&bin_total, sizeof(uint32_t) * (SORT_MAX_CB + 1)));
-    ZK_HIP(hipMalloc(&bin_base, sizeof(uint32_t) * (SORT_MAX_CB + 1)));
-    ZK_HIP(hipMalloc(&sorted, sizeof(uint32_t) * sh.max_entries()));
-    ZK_HIP(hipMalloc(&hist, sizeof(uint32_t) * (sh.nb + 1)));
-    ZK_HIP(hipMalloc(&off, sizeof(uint32_t) * (sh.nb + 1)));
-    ZK_HIP(hipMalloc(&segoff, sizeof(uint32_t) * (sh.nb + 1)));
+    if (!sort_like) {
+        ZK_HIP(hipMalloc(&pairs, sizeof(uint2) * sh.max_entries()));
+        ZK_HIP(hipMalloc(&counts, sizeof(uint32_t) * ((size_t)ss.cb * ss.groups + 1)));
+        ZK_HIP(hipMalloc(&bin_total, sizeof(uint32_t) * (SORT_MAX_CB + 1)));
+        ZK_HIP(hipMalloc(&bin_base, sizeof(uint32_t) * (SORT_MAX_CB + 1)));
+        ZK_HIP(hipMalloc(&sorted, sizeof(uint32_t) * sh.max_entries()));
+        ZK_HIP(hipMalloc(&hist, sizeof(uint32_t) * (sh.nb + 1)));
+        ZK_HIP(hipMalloc(&off, sizeof(uint32_t) * (sh.nb + 1)));
+        ZK_HIP(hipMalloc(&segoff, sizeof(uint32_t) * (sh.nb + 1)));
+        ZK_HIP(hipMalloc(&tile_a, sizeof(uint32_t) * (zk_div_up(sh.nb, SCAN_TILE) + 1)));
+        ZK_HIP(hipMalloc(&tile_b, sizeof(uint32_t) * (zk_div_up(sh.nb, SCAN_TILE) + 1)));
+    }
+    if (sort_only) return ZK_OK;
     ZK_HIP(hipMalloc(&heavy_list, sizeof(uint32_t) * (sh.max_entries() / ((uint64_t)sh.seg * MSM_HEAVY) + 2)));
     ZK_HIP(hipMalloc(&heavy_count, sizeof(uint32_t)));
-    ZK_HIP(hipMalloc(&tile_a, sizeof(uint32_t) * (zk_div_up(sh.nb, SCAN_TILE) + 1)));
-    ZK_HIP(hipMalloc(&tile_b, sizeof(uint32_t) * (zk_div_up(sh.nb, SCAN_TILE) + 1)));
     ZK_HIP(hipMalloc(&segsum, sizeof(typename C::XYZZ) * sh.max_segments()));
     ZK_HIP(hipMalloc(&bucket, sizeof(typename C::XYZZ) * sh.nb));
     ZK_HIP(hipMalloc(&partial_a, sizeof(typename C::XYZZ) * (groups + 1)));
@@ -386,11 +397,9 @@ int MsmWork<C>::precompute(const typename C::Affine *d_bases, uint32_t n, hipStr
 }
 
 template <class C>
-int MsmWork<C>::enqueue(const fe *scalars, const uint32_t *gather, uint32_t n, int canonical, hipStream_t st, hipStream_t st_tail) {
-    if (n != table_n) return ZK_ERR_ARG;                        // the table stride is the precompute-time n
+int MsmWork<C>::enqueue_sort(const fe *scalars, const uint32_t *gather, uint32_t n, int canonical, hipStream_t st) {
+    if (n != table_n || !sorted) return ZK_ERR_ARG;             // the table stride is the precompute-time n
     const uint32_t c = sh.c, W = sh.W, nb = sh.nb, seg = sh.seg;
-    const uint32_t G0 = msm_group(), K = nb < G0 ? nb : G0, groups = nb / K;
-    ZK_HIP(hipMemsetAsync(heavy_count, 0, sizeof(uint32_t), st));
     SortShape sq = ss; sq.set(n ? n : 1, nb);                   // same bins; workgroups sized for this call's n
     ZK_LAUNCH_SYNC(k_sort_count<C>, sq.groups, SORT_THREADS, st, scalars, gather, n, canonical, c, W, sq, counts);
     ZK_LAUNCH_SYNC(k_sort_colscan<C>, sq.cb, SORT_THREADS, st, counts, sq.groups, bin_total);
@@ -404,16 +413,26 @@ int MsmWork<C>::enqueue(const fe *scalars, const uint32_t *gather, uint32_t n, i
         ZK_LAUNCH_SYNC(k_msm_scan_totals<C>, 1, 1024, st, tile_a, tile_b, ntiles);
         ZK_LAUNCH(k_msm_scan_add<C>, zk_div_up(nb + 1, 256), 256, st, nb, ntiles, (const uint32_t *)tile_a, (const uint32_t *)tile_b, off, segoff);
     }
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+}
+
+template <class C>
+int MsmWork<C>::enqueue_reduce(const SortView &v, hipStream_t st, hipStream_t st_tail) {
+    if (!v.sorted || v.seg != sh.seg) return ZK_ERR_ARG;        // a borrowed sort must have this MSM's shape
+    const uint32_t nb = sh.nb, seg = sh.seg;
+    const uint32_t G0 = msm_group(), K = nb < G0 ? nb : G0, groups = nb / K;
+    ZK_HIP(hipMemsetAsync(heavy_count, 0, sizeof(uint32_t), st));
     // segment count is only known on the device: launch for the upper bound, threads past segoff[nb] exit.
-    const uint64_t max_seg = (uint64_t)n * W / seg + nb + 1;
+    const uint64_t max_seg = (uint64_t)v.entries_bound / seg + nb + 1;
+    if (max_seg > sh.max_segments()) return ZK_ERR_ARG;
     ZK_HIP(hipEventRecord(ev_acc0, st));
-    ZK_LAUNCH(k_msm_accumulate<C>, zk_div_up(max_seg, 64), 64, st, (const typename C::Affine *)table, (const uint32_t *)sorted,
-              (const uint32_t *)off, (const uint32_t *)segoff, nb, seg, segsum);
+    ZK_LAUNCH(k_msm_accumulate<C>, zk_div_up(max_seg, 64), 64, st, (const typename C::Affine *)table, v.sorted, v.off, v.segoff,
+              nb, seg, v.remap_src, v.remap_offset, v.remap_pos, table_n, segsum);
     ZK_HIP(hipEventRecord(ev_acc1, st));
     if (st_tail != st) { ZK_HIP(hipStreamWaitEvent(st_tail, ev_acc1, 0)); st = st_tail; }
-    ZK_LAUNCH(k_msm_bucket_finalize<C>, zk_div_up(nb, 64), 64, st, (const typename C::XYZZ *)segsum,
-              (const uint32_t *)segoff, nb, bucket, heavy_list, heavy_count);
-    ZK_LAUNCH_SYNC(k_msm_heavy<C>, MSM_HEAVY_GRID, 128, st, (const typename C::XYZZ *)segsum, (const uint32_t *)segoff,
+    ZK_LAUNCH(k_msm_bucket_finalize<C>, zk_div_up(nb, 64), 64, st, (const typename C::XYZZ *)segsum, v.segoff, nb, bucket, heavy_list, heavy_count);
+    ZK_LAUNCH_SYNC(k_msm_heavy<C>, MSM_HEAVY_GRID, 128, st, (const typename C::XYZZ *)segsum, v.segoff,
                    (const uint32_t *)heavy_list, (const uint32_t *)heavy_count, bucket);
     ZK_LAUNCH(k_msm_group_reduce<C>, zk_div_up(groups, 64), 64, st, (const typename C::XYZZ *)bucket, nb, K, partial_a);
     typename C::XYZZ *cur = partial_a, *nxt = partial_b;
@@ -427,6 +446,12 @@ int MsmWork<C>::enqueue(const fe *scalars, const uint32_t *gather, uint32_t n, i
     ZK_HIP(hipGetLastError());
     ZK_HIP(hipMemcpyAsync(host_result, cur, sizeof(typename C::XYZZ), hipMemcpyDeviceToHost, st));
     return ZK_OK;
+}
+
+template <class C>
+int MsmWork<C>::enqueue(const fe *scalars, const uint32_t *gather, uint32_t n, int canonical, hipStream_t st, hipStream_t st_tail) {
+    ZK_TRY(enqueue_sort(scalars, gather, n, canonical, st));
+    return enqueue_reduce(view(), st, st_tail);
 }
 
 }  // namespace zk

@@ -301,6 +301,12 @@ struct DeviceTables {
     uint64_t pk_id = 0; int device = 0; uint32_t rank = 0, count = 1, cbits = 0;
     G1::Affine *tA = nullptr, *tH = nullptr, *tL = nullptr; G2::Affine *tB = nullptr;
     uint32_t *dA_idx = nullptr, *dB_idx = nullptr;
+    // the A-, B- and L-query all read the witness: ONE bucket sort of all V+1 witness digits drives every query that
+    // holds at least 7/8 of the variables (absent entries are skipped lane-locally); sparser queries and sharded
+    // contexts sort their own scalars
+    bool share_A = false, share_B = false, share_L = false;
+    uint32_t *posA = nullptr, *posB = nullptr;         // witness index -> query entry (0xffffffff: the query has none)
+    uint32_t cW = 0;                                   // window bits of the shared witness sort and of the tables it drives
     int refs = 0;
 };
 std::mutex g_tables_mu;
@@ -324,7 +330,7 @@ void tables_release(DeviceTables *t) {
     std::lock_guard<std::mutex> lk(g_tables_mu);
     if (--t->refs > 0) return;
     hipSetDevice(t->device);
-    void *dev[] = {t->tA, t->tH, t->tL, t->tB, t->dA_idx, t->dB_idx};
+    void *dev[] = {t->tA, t->tH, t->tL, t->tB, t->dA_idx, t->dB_idx, t->posA, t->posB};
     for (void *p : dev) if (p) hipFree(p);
     for (size_t i = 0; i < g_tables.size(); i++) if (g_tables[i] == t) { g_tables.erase(g_tables.begin() + i); break; }
     delete t;
@@ -347,7 +353,7 @@ struct zk_ctx {
     fe *h_w = nullptr;                         // pinned staging for the witness
     fe *h_tail = nullptr;                      // pinned: h[m-1] for the degree check
     NttTables tab;
-    MsmWork<G1> mA, mH, mL; MsmWork<G2> mB;
+    MsmWork<G1> mA, mH, mL, mW; MsmWork<G2> mB;       // mW: sort-only, the shared witness-digit sort
     hipStream_t s_main = nullptr, s_a = nullptr, s_b = nullptr, s_l = nullptr;
     hipEvent_t ev_start = nullptr, ev_w = nullptr, ev_h = nullptr, ev_a0 = nullptr, ev_a1 = nullptr, ev_b0 = nullptr, ev_b1 = nullptr,
                ev_l0 = nullptr, ev_l1 = nullptr, ev_h1 = nullptr, ev_h0 = nullptr;
@@ -359,7 +365,7 @@ struct zk_ctx {
         if (h_tail) hipHostFree(h_tail);
         cA.release(); cB.release(); cC.release();
         ntt_tables_free(tab);
-        mA.release(); mH.release(); mL.release(); mB.release();
+        mA.release(); mH.release(); mL.release(); mB.release(); mW.release();
         tables_release(tables);
         if (serial) s_a = s_b = s_l = nullptr;
         hipStream_t ss[] = {s_main, s_a, s_b, s_l};
@@ -392,14 +398,28 @@ static int ctx_build(zk_ctx *c, const zk_pk *pk, const zk_csr *A, const zk_csr *
             t = new (std::nothrow) DeviceTables();
             if (!t) return ZK_ERR_NOMEM;
             t->pk_id = pk->id; t->device = c->device; t->rank = r; t->count = G; t->cbits = c->cfg.multi_exp_c;
+            const uint64_t dense = ((uint64_t)V + 1) * 7 / 8;
+            const bool can_share = G == 1 && V + 1 >= 64 && !getenv("ZK_NO_SHARED_SORT");
+            t->share_A = can_share && pk->a_val.size() >= dense;
+            t->share_B = can_share && pk->b_val.size() >= dense;
+            t->share_L = can_share && (uint64_t)(V - nIn) >= dense;
+            if ((int)t->share_A + (int)t->share_B + (int)t->share_L < 2) t->share_A = t->share_B = t->share_L = false;   // nothing to share
+            t->cW = t->cbits ? t->cbits : MsmShape::pick_c(V + 1);
             int rc = dev_upload(&t->dA_idx, pk->a_idx.data() + c->rA.lo, c->rA.n());
             if (rc == ZK_OK) rc = dev_upload(&t->dB_idx, pk->b_idx.data() + c->rB.lo, c->rB.n());
-            if (rc == ZK_OK) rc = build_table<G1>(&t->tA, pk->a_val.data() + c->rA.lo, c->rA.n(), t->cbits);
+            auto inverse = [&](const std::vector<uint32_t> &idx, uint32_t **out) -> int {
+                std::vector<uint32_t> pos((size_t)V + 1, 0xffffffffu);
+                for (size_t k = 0; k < idx.size(); k++) pos[idx[k]] = (uint32_t)k;
+                return dev_upload(out, pos.data(), pos.size());
+            };
+            if (rc == ZK_OK && t->share_A) rc = inverse(pk->a_idx, &t->posA);
+            if (rc == ZK_OK && t->share_B) rc = inverse(pk->b_idx, &t->posB);
+            if (rc == ZK_OK) rc = build_table<G1>(&t->tA, pk->a_val.data() + c->rA.lo, c->rA.n(), t->share_A ? t->cW : t->cbits);
             if (rc == ZK_OK) rc = build_table<G1>(&t->tH, pk->H.data() + c->rH.lo, c->rH.n(), t->cbits);
-            if (rc == ZK_OK) rc = build_table<G1>(&t->tL, pk->L.data() + c->rL.lo, c->rL.n(), t->cbits);
-            if (rc == ZK_OK) rc = build_table<G2>(&t->tB, pk->b_val.data() + c->rB.lo, c->rB.n(), t->cbits);
+            if (rc == ZK_OK) rc = build_table<G1>(&t->tL, pk->L.data() + c->rL.lo, c->rL.n(), t->share_L ? t->cW : t->cbits);
+            if (rc == ZK_OK) rc = build_table<G2>(&t->tB, pk->b_val.data() + c->rB.lo, c->rB.n(), t->share_B ? t->cW : t->cbits);
             if (rc != ZK_OK) {
-                void *dev[] = {t->tA, t->tH, t->tL, t->tB, t->dA_idx, t->dB_idx};
+                void *dev[] = {t->tA, t->tH, t->tL, t->tB, t->dA_idx, t->dB_idx, t->posA, t->posB};
                 for (void *p : dev) if (p) hipFree(p);
                 delete t;
                 return rc;
@@ -410,10 +430,13 @@ static int ctx_build(zk_ctx *c, const zk_pk *pk, const zk_csr *A, const zk_csr *
         c->tables = t;
     }
     c->dA_idx = c->tables->dA_idx; c->dB_idx = c->tables->dB_idx;
-    ZK_TRY(c->mA.alloc(c->rA.n(), c->cfg.multi_exp_c, c->tables->tA));
-    ZK_TRY(c->mH.alloc(c->rH.n(), c->cfg.multi_exp_c, c->tables->tH));
-    ZK_TRY(c->mL.alloc(c->rL.n(), c->cfg.multi_exp_c, c->tables->tL));
-    ZK_TRY(c->mB.alloc(c->rB.n(), c->cfg.multi_exp_c, c->tables->tB));
+    const DeviceTables *t = c->tables;
+    const bool any_share = t->share_A || t->share_B || t->share_L;
+    if (any_share) ZK_TRY(c->mW.alloc(V + 1, t->cW, nullptr, nullptr, /*sort_only=*/true));
+    ZK_TRY(c->mA.alloc(c->rA.n(), c->cfg.multi_exp_c, t->tA, t->share_A ? &c->mW.sh : nullptr));
+    ZK_TRY(c->mH.alloc(c->rH.n(), c->cfg.multi_exp_c, t->tH));
+    ZK_TRY(c->mL.alloc(c->rL.n(), c->cfg.multi_exp_c, t->tL, t->share_L ? &c->mW.sh : nullptr));
+    ZK_TRY(c->mB.alloc(c->rB.n(), c->cfg.multi_exp_c, t->tB, t->share_B ? &c->mW.sh : nullptr));
     ZK_TRY(c->cA.upload(A, V)); ZK_TRY(c->cB.upload(B, V)); ZK_TRY(c->cC.upload(C, V));
     ZK_HIP(hipMalloc(&c->d_w, 32 * (size_t)(V + 1)));
     ZK_HIP(hipMalloc(&c->d_a, 32 * (size_t)m)); ZK_HIP(hipMalloc(&c->d_b, 32 * (size_t)m));
@@ -510,14 +533,19 @@ static int prove_submit_impl(zk_ctx *c, const uint64_t *witness, int canonical) 
     // and L-query run on side streams beside the next accumulation.  Longest tail (G2) first; the H-query is
     // last and keeps its tail on the main stream.
     hipStream_t m = c->s_main;
+    const DeviceTables *t = c->tables;
+    if (t->share_A || t->share_B || t->share_L) ZK_TRY(c->mW.enqueue_sort(c->d_w, nullptr, c->V + 1, 0, m));   // one sort of all witness digits
     ZK_HIP(hipEventRecord(c->ev_b0, m));
-    ZK_TRY(c->mB.enqueue(c->d_w, c->dB_idx, c->rB.n(), 0, m, c->s_b));                          // tcc:499-506
+    if (t->share_B) ZK_TRY(c->mB.enqueue_reduce(c->mW.view_for(0, t->posB), m, c->s_b));         // tcc:499-506
+    else ZK_TRY(c->mB.enqueue(c->d_w, c->dB_idx, c->rB.n(), 0, m, c->s_b));
     ZK_HIP(hipEventRecord(c->ev_b1, c->s_b));
     ZK_HIP(hipEventRecord(c->ev_a0, m));
-    ZK_TRY(c->mA.enqueue(c->d_w, c->dA_idx, c->rA.n(), 0, m, c->s_a));                          // tcc:488-495
+    if (t->share_A) ZK_TRY(c->mA.enqueue_reduce(c->mW.view_for(0, t->posA), m, c->s_a));         // tcc:488-495
+    else ZK_TRY(c->mA.enqueue(c->d_w, c->dA_idx, c->rA.n(), 0, m, c->s_a));
     ZK_HIP(hipEventRecord(c->ev_a1, c->s_a));
     ZK_HIP(hipEventRecord(c->ev_l0, m));
-    ZK_TRY(c->mL.enqueue(c->d_w + (c->nIn + 1) + c->rL.lo, nullptr, c->rL.n(), 0, m, c->s_l)); // tcc:522-530
+    if (t->share_L) ZK_TRY(c->mL.enqueue_reduce(c->mW.view_for(c->nIn + 1), m, c->s_l));         // tcc:522-530
+    else ZK_TRY(c->mL.enqueue(c->d_w + (c->nIn + 1) + c->rL.lo, nullptr, c->rL.n(), 0, m, c->s_l));
     ZK_HIP(hipEventRecord(c->ev_l1, c->s_l));
     ZK_HIP(hipEventRecord(c->ev_h0, m));
     ZK_TRY(enqueue_compute_h(c));
