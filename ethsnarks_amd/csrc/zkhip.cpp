@@ -408,6 +408,9 @@ static int ctx_build(zk_ctx *c, const zk_pk *pk, const zk_csr *A, const zk_csr *
             int rc = dev_upload(&t->dA_idx, pk->a_idx.data() + c->rA.lo, c->rA.n());
             if (rc == ZK_OK) rc = dev_upload(&t->dB_idx, pk->b_idx.data() + c->rB.lo, c->rB.n());
             auto inverse = [&](const std::vector<uint32_t> &idx, uint32_t **out) -> int {
+                bool prefix = true;                                  // entries 0..n-1 in place: index == position, no map needed
+                for (size_t k = 0; k < idx.size() && prefix; k++) prefix = idx[k] == k;
+                if (prefix) { *out = nullptr; return ZK_OK; }
                 std::vector<uint32_t> pos((size_t)V + 1, 0xffffffffu);
                 for (size_t k = 0; k < idx.size(); k++) pos[idx[k]] = (uint32_t)k;
                 return dev_upload(out, pos.data(), pos.size());
