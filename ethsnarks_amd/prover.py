@@ -56,7 +56,7 @@ class ZkTimings(C.Structure):
 
 EXPORTS = [
     "zk_version", "zk_strerror", "zk_last_error", "zk_device_count",
-    "zk_pk_load_raw", "zk_pk_save_raw", "zk_pk_from_parts", "zk_pk_sizes", "zk_pk_part", "zk_pk_free",
+    "zk_pk_load_raw", "zk_pk_save_raw", "zk_pk_from_bellman_json", "zk_pk_bellman2ethsnarks", "zk_pk_from_parts", "zk_pk_sizes", "zk_pk_part", "zk_pk_free",
     "zk_keygen", "zk_vk_to_json", "zk_vk_free",
     "zk_domain_size", "zk_ctx_create", "zk_ctx_destroy",
     "zk_prove", "zk_prove_timed", "zk_prove_partial", "zk_prove_partial_timed", "zk_prove_combine", "zk_prove_submit", "zk_prove_collect", "zk_proof_to_json",
@@ -170,6 +170,20 @@ def load_proving_key(pk_file, codec=0):
     h = C.c_void_p()
     _check(lib.zk_pk_load_raw(os.fsencode(pk_file), codec, C.byref(h)))
     return ProvingKey(h)
+
+
+def load_bellman_proving_key(json_file):
+    """proving key from a bellman / snarkjs style JSON, mapped as pk_bellman2ethsnarks does (src/export.cpp:267-321)."""
+    lib = load_library(_lib_path_loaded)
+    h = C.c_void_p()
+    _check(lib.zk_pk_from_bellman_json(os.fsencode(json_file), C.byref(h)))
+    return ProvingKey(h)
+
+
+def pk_bellman2ethsnarks(bellman_pk_file, pk_file):
+    """pk_bellman2ethsnarks (src/export.cpp:267-328): JSON in, nozk `.raw` out; True on success like the reference."""
+    _check(load_library(_lib_path_loaded).zk_pk_bellman2ethsnarks(os.fsencode(bellman_pk_file), os.fsencode(pk_file)))
+    return True
 
 
 class VerificationKey:

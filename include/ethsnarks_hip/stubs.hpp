@@ -88,6 +88,14 @@ inline ProvingKeyT load_proving_key(const char *pk_file) {
     return ProvingKeyT(h);
 }
 
+// pk_bellman2ethsnarks (src/export.hpp:24, src/export.cpp:267-328): bellman-style JSON key -> nozk `.raw`.
+// The reference returns true even when the input cannot be opened (it only prints); here that is `false`.
+inline bool pk_bellman2ethsnarks(const std::string &bellman_pk_file, const std::string &pk_file) {
+    const int rc = zk_pk_bellman2ethsnarks(bellman_pk_file.c_str(), pk_file.c_str());
+    if (rc != ZK_OK) std::cerr << "pk_bellman2ethsnarks: " << zk_strerror(rc) << ": " << zk_last_error() << std::endl;
+    return rc == ZK_OK;
+}
+
 // the "domain" of the reference is an evaluation_domain object; here it is a property of the context.
 struct DomainT { uint32_t m; };
 

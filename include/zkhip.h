@@ -7,6 +7,7 @@
  *                          loadFromFile<ProvingKeyT>                         src/utils.hpp:176-185
  *                          operator>>(istream&, pk_nozk&)                    r1cs_gg_ppzksnark_zok.tcc:124-143
  *   zk_pk_save_raw      <- writeToFile<ProvingKeyT> / operator<<             src/utils.hpp:166-173, tcc:108-122
+ *   zk_pk_from_bellman_json / zk_pk_bellman2ethsnarks <- pk_bellman2ethsnarks + readG1/readG2   src/export.cpp:223-328
  *   zk_pk_from_parts    <- r1cs_gg_ppzksnark_zok_proving_key_nozk ctor       r1cs_gg_ppzksnark_zok.hpp:171-233
  *   zk_ctx_create       <- ProverContext<ppT>(pk) + get_domain(pb, pk, cfg)  hpp:279-291, src/stubs.cpp:61-75
  *   zk_prove            <- r1cs_gg_ppzksnark_zok_prover(ctx, pb.values)      tcc:451-550 (via prove(), stubs.cpp:42-47)
@@ -102,6 +103,11 @@ int zk_device_count(int *count);
 /* ---- proving key (host object; zk_ctx_create uploads it) */
 int zk_pk_load_raw(const char *path, int codec, zk_pk **out);
 int zk_pk_save_raw(const zk_pk *pk, const char *path, int codec);
+/* bellman / snarkjs style proving-key JSON (keys A, B1, B2, C, hExps, vk_alfa_1, vk_beta_1/2, vk_delta_1/2; Jacobian
+ * decimal triples) -> nozk key, exactly as pk_bellman2ethsnarks maps it (one public input: L = C[2..]);
+ * zk_pk_bellman2ethsnarks writes the `.raw` file the reference's converter writes */
+int zk_pk_from_bellman_json(const char *json_path, zk_pk **out);
+int zk_pk_bellman2ethsnarks(const char *bellman_pk_json, const char *pk_raw);
 int zk_pk_from_parts(const uint64_t *alpha_g1, const uint64_t *beta_g1, const uint64_t *beta_g2,
                      const uint64_t *delta_g1, const uint64_t *delta_g2,
                      uint32_t a_domain, uint32_t nA, const uint32_t *a_idx, const uint64_t *a_val,

@@ -332,3 +332,36 @@ def vk_to_json_dict(vk):
     g2 = lambda p: [[_hx(p[0][1]), _hx(p[0][0])], [_hx(p[1][1]), _hx(p[1][0])]]
     return {"alpha": g1(vk["alpha_g1"]), "beta": g2(vk["beta_g2"]), "gamma": g2(vk["gamma_g2"]),
             "delta": g2(vk["delta_g2"]), "gammaABC": [g1(p) for p in vk["gamma_abc"]]}
+
+
+# ------------------------------------------------------------------ bellman-style proving-key JSON
+def _jac_g1(a):
+    """readG1 (src/export.cpp:223-236): Jacobian decimal triple -> affine (None = zero)"""
+    x, y, z = (int(v) % Q for v in a)
+    if z == 0: return None
+    zi = pow(z, -1, Q)
+    return (x * zi * zi % Q, y * zi * zi % Q * zi % Q)
+
+
+def _jac_g2(a):
+    """readG2 (src/export.cpp:238-265): [[x.c0, x.c1], [y.c0, y.c1], [z.c0, z.c1]] -> affine"""
+    x, y, z = ((int(v[0]) % Q, int(v[1]) % Q) for v in a)
+    if z == (0, 0): return None
+    zi = f2_inv(z); zi2 = f2_mul(zi, zi)
+    return (f2_mul(x, zi2), f2_mul(y, f2_mul(zi2, zi)))
+
+
+def pk_from_bellman_json(d):
+    """pk_bellman2ethsnarks (src/export.cpp:267-321) + the nozk conversion (hpp:209-233) on a parsed JSON dict:
+    A keeps its non-zero entries, B keeps B2[i] where B1[i] is non-zero (domain |A|), L = C[2..], H = hExps.
+    Returns the pk dict of keygen() plus the two domain sizes; points are affine or None."""
+    A = [_jac_g1(p) for p in d["A"]]
+    B1 = [_jac_g1(p) for p in d["B1"]]
+    B2 = [_jac_g2(p) for p in d["B2"]]
+    keepA = [i for i, p in enumerate(A) if p is not None]
+    keepB = [i for i, p in enumerate(B1) if p is not None]
+    return dict(alpha_g1=_jac_g1(d["vk_alfa_1"]), beta_g1=_jac_g1(d["vk_beta_1"]), beta_g2=_jac_g2(d["vk_beta_2"]),
+                delta_g1=_jac_g1(d["vk_delta_1"]), delta_g2=_jac_g2(d["vk_delta_2"]),
+                A=(keepA, [A[i] for i in keepA]), B=(keepB, [B2[i] for i in keepB]),
+                H=[_jac_g1(p) for p in d["hExps"]], L=[_jac_g1(p) for p in d["C"][2:]],
+                a_domain=len(A), b_domain=len(A))
