@@ -32,11 +32,16 @@
 
 namespace zk {
 
-constexpr uint32_t MSM_SEG_MIN = 32;      // entries per accumulation thread (lower bound)
+constexpr uint32_t MSM_SEG_MIN = 32;      // entries per accumulation thread (lower bound) when the entries fill the machine
+constexpr uint32_t MSM_SEG_MIN_SMALL = 8; // ... and for MSMs of <= 2^23 entries, whose time is the serial chain per thread, not throughput
 constexpr uint32_t MSM_SEG_PER_BUCKET = 16;   // target segments per bucket (sets the segment length)
 constexpr uint32_t MSM_HEAVY = 64;        // buckets with more segments than this are reduced by a workgroup
 constexpr uint32_t MSM_GROUP = 8;         // buckets per running-sum thread (ZK_MSM_GROUP overrides: tuning aid)
-inline uint32_t msm_group() { if (const char *e = getenv("ZK_MSM_GROUP")) { int v = atoi(e); if (v >= 1 && v <= 1024) return (uint32_t)v; } return MSM_GROUP; }
+constexpr uint32_t MSM_GROUP_SMALL = 4;   // ... for <= 2^15 buckets (latency-bound sizes; measured at 2^12 / 2^15 / 2^18, tools/dev_small_sweep.sh)
+inline uint32_t msm_group(uint32_t nb) {
+    if (const char *e = getenv("ZK_MSM_GROUP")) { int v = atoi(e); if (v >= 1 && v <= 1024) return (uint32_t)v; }
+    return nb <= (1u << 15) ? MSM_GROUP_SMALL : MSM_GROUP;
+}
 constexpr uint32_t MSM_TREE = 256;        // fan-in (= workgroup size) of the final tree sum
 #ifdef ZK_EMUL
 constexpr uint32_t MSM_HEAVY_GRID = 2;    // the emulator spawns a real thread per GPU thread
@@ -79,7 +84,7 @@ struct MsmShape {
         if (c < 2) c = 2;
         if (c > 20) c = 20;
         W = 254 / c + 1; nb = 1u << (c - 1);
-        seg = MSM_SEG_MIN;
+        seg = max_entries() <= (1ull << 23) ? MSM_SEG_MIN_SMALL : MSM_SEG_MIN;
         if (const char *e = getenv("ZK_SEG_MIN")) { int v = atoi(e); if (v >= 4) seg = (uint32_t)v; }                // tuning aid
         uint32_t spb = MSM_SEG_PER_BUCKET;
         if (const char *e = getenv("ZK_SEG_PER_BUCKET")) { int v = atoi(e); if (v > 0) spb = (uint32_t)v; }   // tuning aid

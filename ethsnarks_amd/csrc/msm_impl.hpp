@@ -347,7 +347,7 @@ template <class C>
 int MsmWork<C>::alloc(uint32_t n, uint32_t c, typename C::Affine *shared_table, const MsmShape *sort_like, bool sort_only) {
     if (sort_like) sh = *sort_like; else sh.set(n ? n : 1, c);
     if (sh.max_entries() >= (1ull << 31)) return ZK_ERR_ARG;     // entry payload = table index (31 bits) | sign
-    const uint32_t G0 = msm_group(), K = sh.nb < G0 ? sh.nb : G0, groups = sh.nb / K;
+    const uint32_t G0 = msm_group(sh.nb), K = sh.nb < G0 ? sh.nb : G0, groups = sh.nb / K;
     if (sort_only) { owns_table = false; table_n = n; }
     else if (shared_table) { table = shared_table; owns_table = false; table_n = n; }
     else ZK_HIP(hipMalloc(&table, sizeof(typename C::Affine) * (size_t)(n ? n : 1) * sh.W));
@@ -421,7 +421,7 @@ template <class C>
 int MsmWork<C>::enqueue_reduce(const SortView &v, hipStream_t st, hipStream_t st_tail) {
     if (!v.sorted || v.seg != sh.seg) return ZK_ERR_ARG;        // a borrowed sort must have this MSM's shape
     const uint32_t nb = sh.nb, seg = sh.seg;
-    const uint32_t G0 = msm_group(), K = nb < G0 ? nb : G0, groups = nb / K;
+    const uint32_t G0 = msm_group(nb), K = nb < G0 ? nb : G0, groups = nb / K;
     ZK_HIP(hipMemsetAsync(heavy_count, 0, sizeof(uint32_t), st));
     // segment count is only known on the device: launch for the upper bound, threads past segoff[nb] exit.
     const uint64_t max_seg = (uint64_t)v.entries_bound / seg + nb + 1;
