@@ -13,8 +13,10 @@
 // so that a gadget binary written against ethsnarks keeps its source: it includes this header instead of
 // "stubs.hpp" and links libzkhip.so instead of libsnark's prover.  The libsnark *front end* (protoboard,
 // gadgets, r1cs_constraint_system) stays what it was; only the proving key container, the prover context
-// and the prover itself are replaced.  Requires the libsnark/libff headers of the ethsnarks build
-// (they are not vendored here; the reference checkout itself ships them as empty submodules).
+// and the prover itself are replaced.  Where the libsnark/libff headers of the ethsnarks build are on the include
+// path they are used; where they are not (the reference checkout itself ships them as empty submodules) the
+// stand-alone front end of ethsnarks_hip/circuit.hpp supplies the same names, so the adapter -- and gadget
+// code written against that surface, ethsnarks_hip/gadgets.hpp -- compiles and runs either way.
 //
 // The adapter flattens pb.constraint_system once per context through the accessor chain the reference's
 // own dumper uses (src/export.cpp:157-190: constraints[c]->getA().getTerms() -> {index, getCoeff()}),
@@ -25,6 +27,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <iterator>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iostream>
@@ -32,12 +35,14 @@
 #include <stdexcept>
 #include <string>
 #include <vector>
+#include <unistd.h>
 
 #if __has_include(<libsnark/gadgetlib1/protoboard.hpp>)
 #include <libsnark/gadgetlib1/protoboard.hpp>
 #include "ethsnarks.hpp"          // FieldT, ProtoboardT, ppT (src/ethsnarks.hpp:31-48)
 #define ETHSNARKS_HIP_HAVE_LIBSNARK 1
 #else
+#include "circuit.hpp"            // stand-alone front end with the same surface (FieldT, ProtoboardT, VariableT, ...)
 #define ETHSNARKS_HIP_HAVE_LIBSNARK 0
 #endif
 
@@ -108,7 +113,6 @@ struct ProverContextT {
     explicit ProverContextT(ProvingKeyT &pk) : provingKey(pk) {}
 };
 
-#if ETHSNARKS_HIP_HAVE_LIBSNARK
 namespace detail {
 struct Flat { std::vector<uint32_t> ptr, col; std::vector<uint64_t> coeff; };
 template <class LC> void push_row(Flat &f, const LC &lc) {
@@ -196,7 +200,12 @@ inline int stub_genkeys_from_pb(ProtoboardT &pb, const char *pk_file, const char
 // stub_test_proof_verify (src/stubs.cpp:135-148): keygen -> prove -> verify in memory.  Unlike the reference it
 // sets up the whole context (the reference leaves constraint_system and domain unset).
 inline bool stub_test_proof_verify(ProtoboardT &pb) {
-    const std::string pk_tmp = std::string(std::tmpnam(nullptr)) + ".raw", vk_tmp = pk_tmp + ".vk.json";
+    const char *tmpdir = std::getenv("TMPDIR");
+    std::string tmpl = std::string(tmpdir && *tmpdir ? tmpdir : "/tmp") + "/zkhip_pk_XXXXXX";
+    const int fd = mkstemp(&tmpl[0]);
+    if (fd < 0) return false;
+    close(fd);
+    const std::string pk_tmp = tmpl, vk_tmp = pk_tmp + ".vk.json";
     if (stub_genkeys_from_pb(pb, pk_tmp.c_str(), vk_tmp.c_str()) != 0) return false;
     std::ifstream vf(vk_tmp, std::ios::binary);
     const std::string vk((std::istreambuf_iterator<char>(vf)), std::istreambuf_iterator<char>());
@@ -226,6 +235,4 @@ int stub_main_prove(const char *prog_name, int argc, char **argv) {
         return 1;
     }
 }
-#endif  // ETHSNARKS_HIP_HAVE_LIBSNARK
-
 }  // namespace ethsnarks

@@ -1,0 +1,78 @@
+"""The C++ side of the boundary: include/ethsnarks_hip/stubs.hpp (the adapter with the reference's function names)
+on top of the stand-alone front end (circuit.hpp) and the MiMC / Merkle gadgets (gadgets.hpp), driven by
+tests/cpp/frontend_test.cpp, which is written like the reference's own gadget tests.
+
+CPU: the program compiles with plain g++ against the C ABI, the reference's known answers hold in C++, and the
+depth-29 Merkle circuit it builds is the same R1CS + witness as the Python front end's (two independent restatements
+of src/gadgets/{mimc,onewayfunction,merkle_tree}.*).
+GPU: stub_genkeys_from_pb -> stub_prove_from_pb -> stub_verify through the adapter; the proof is byte-identical to the
+CPU oracle's for the key the adapter wrote."""
+import json
+import os
+import subprocess
+import numpy as np
+import pytest
+from conftest import ROOT
+from ethsnarks_amd import gadgets as G, r1cs as R, fields as F
+
+LIB = os.path.join(ROOT, "ethsnarks_amd", "libzkhip.so")
+pytestmark = pytest.mark.skipif(not os.path.exists(LIB), reason="libzkhip.so not built (run __graft_entry__.build())")
+
+
+@pytest.fixture(scope="module")
+def exe(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("cpp") / "frontend_test")
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "cpp", "frontend_test.cpp"), "-o", out,
+           "-L" + os.path.join(ROOT, "ethsnarks_amd"), "-lzkhip", "-Wl,-rpath," + os.path.join(ROOT, "ethsnarks_amd")]
+    p = subprocess.run(cmd, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    return out
+
+
+def _rows(csr):
+    out = []
+    for row in csr.to_rows():
+        d = {}
+        for i, c in row:
+            d[i] = (d.get(i, 0) + c) % F.FR
+        out.append({i: c for i, c in d.items() if c})
+    return out
+
+
+def test_reference_known_answers_hold_in_cpp(exe):
+    p = subprocess.run([exe, "kat"], capture_output=True, text=True)
+    assert p.returncode == 0 and p.stdout.strip() == "OK", p.stderr
+
+
+def test_cpp_and_python_front_ends_build_the_same_circuit(exe, tmp_path):
+    rj, wj = str(tmp_path / "r1cs.json"), str(tmp_path / "witness.json")
+    p = subprocess.run([exe, "dump", rj, wj], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    r_cpp = R.r1cs_from_json(open(rj).read())              # the reference's r1cs2json schema (src/export.cpp:173-206)
+    w_cpp = R.witness_from_json(open(wj).read())
+    r_py, w_py, root = G.merkle_membership_circuit(29)
+    assert (r_cpp.nC, r_cpp.nIn, r_cpp.V) == (r_py.nC, r_py.nIn, r_py.V) == (21345, 1, r_py.V)
+    assert w_cpp == [int(v) for v in w_py] and w_cpp[1] == root
+    for a, b in ((r_cpp.A, r_py.A), (r_cpp.B, r_py.B), (r_cpp.C, r_py.C)):
+        assert _rows(a) == _rows(b)
+
+
+@pytest.mark.gpu
+def test_adapter_genkeys_prove_verify_matches_oracle(exe, oracle, tmp_path):
+    pk, vk, pj = str(tmp_path / "pk.raw"), str(tmp_path / "vk.json"), str(tmp_path / "proof.json")
+    p = subprocess.run([exe, "prove", pk, vk, pj], capture_output=True, text=True)
+    assert p.returncode == 0 and p.stdout.strip() == "VERIFIED", p.stdout + p.stderr
+    proof = open(pj).read()
+    r, w, root = G.merkle_membership_circuit(29)
+    assert int(json.loads(proof)["input"][0], 16) == root
+    expect, _ = oracle.prove(oracle.read_raw(pk), r, F.fr_to_mont(w))    # same key file, CPU oracle
+    assert proof == expect
+    import pyref
+    assert pyref.verify(json.loads(open(vk).read()), json.loads(proof))
+
+
+@pytest.mark.gpu
+def test_adapter_stub_test_proof_verify(exe):
+    p = subprocess.run([exe, "roundtrip"], capture_output=True, text=True)
+    assert p.returncode == 0 and p.stdout.strip() == "VERIFIED", p.stdout + p.stderr
