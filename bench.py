@@ -43,6 +43,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--logm", type=int, default=20, help="domain size 2^logm (nC = 2^logm - 2)")
     ap.add_argument("--mode", choices=["shard", "replicas"], default="replicas")
+    ap.add_argument("--workload", choices=["chain", "merkle29", "mimc11"], default="chain",
+                    help="chain: the headline synthetic R1CS (configs 2/3/5 by --logm); merkle29 / mimc11: BASELINE configs 4 / 1 "
+                         "(real MiMC circuits from ethsnarks_amd.gadgets; latency-sized, not the headline)")
     ap.add_argument("--multi-exp-c", type=int, default=0)
     ap.add_argument("--inflight", type=int, default=3,
                     help="prover contexts kept in flight per GPU (1 = one synchronous proof at a time; 2 overlaps the "
@@ -81,7 +84,17 @@ def main():
     logm = args.logm
     nC = (1 << logm) - 2
     t0 = time.time()
-    r1cs, w_ints = R.synthetic_chain(nC, 1)
+    if args.workload == "chain":
+        r1cs, w_ints = R.synthetic_chain(nC, 1)
+        workload = "synthetic chain R1CS (SURVEY 8d), nC=2^%d-2=%d, nIn=1, V=%d, domain m=2^%d; real seeded Groth16 key" % (logm, nC, r1cs.V, logm)
+    else:
+        from ethsnarks_amd import gadgets as G
+        r1cs, w_ints, _ = G.merkle_membership_circuit(29) if args.workload == "merkle29" else G.mimc_preimage_circuit(11)
+        nC = r1cs.nC
+        logm = r1cs.domain_size.bit_length() - 1
+        workload = "%s (BASELINE config %s): nC=%d, nIn=%d, V=%d, domain m=2^%d; real seeded Groth16 key" % (
+            "merkle_path_authenticator<MiMC_e7_hash_gadget> depth 29" if args.workload == "merkle29" else "MiMC-e7 hash preimage, 11 words",
+            "4" if args.workload == "merkle29" else "1", nC, r1cs.nIn, r1cs.V, logm)
     wm = F.fr_to_mont(w_ints)
     t_circuit = time.time() - t0
     t0 = time.time()
@@ -176,7 +189,7 @@ def main():
             "scaling": "strong" if shard else "weak", "vs_baseline": None,
             "dtype": "u32 (8-limb 254-bit Montgomery integers)", "data": "synthetic",
             "constraints_per_sec": round(value * nC, 1),
-            "config": {"workload": "synthetic chain R1CS (SURVEY 8d), nC=2^%d-2=%d, nIn=1, V=%d, domain m=2^%d; real seeded Groth16 key" % (logm, nC, r1cs.V, logm),
+            "config": {"workload": workload,
                        "parallelism": ("msm-shard%d+allgather640B" % world) if shard else ("replicas%d" % world if world > 1 else "1gpu"),
                        "multi_exp_c": args.multi_exp_c or P_pick_c(nB_local), "witness": "host buffer, H2D inside the timed region", "inflight": max(1, args.inflight)},
             "roofline": {"kernel": "k_msm_accumulate<G2> (B-query bucket accumulation)", "bound": "hbm",
