@@ -73,6 +73,8 @@ struct SortShape {
 
 struct MsmShape {
     uint32_t n = 0, c = 0, W = 0, nb = 0, seg = MSM_SEG_MIN;
+    uint32_t quad = 1;      // lanes per logical thread in the bucket-reduction kernels: 1, or 4 (Curve::*_q) for latency-bound sizes
+    uint32_t quad_acc = 1;  // ... and in the accumulation kernel (only while 4 lanes per segment still fit the machine at once)
     // largest window with >= 32 entries per bucket on average (n * W entries over 2^(c-1) buckets)
     static uint32_t pick_c(uint32_t n) {
         for (uint32_t c = 17; c > 2; c--)      // 17: measured optimum at n = 2^20 (W = 15 windows, 2^16 buckets)
@@ -89,6 +91,12 @@ struct MsmShape {
         uint32_t spb = MSM_SEG_PER_BUCKET;
         if (const char *e = getenv("ZK_SEG_PER_BUCKET")) { int v = atoi(e); if (v > 0) spb = (uint32_t)v; }   // tuning aid
         while (seg < 4096 && (uint64_t)seg * nb * spb < max_entries()) seg <<= 1;
+        // measured (tools/dev_small_sweep.sh, domains 2^13 .. 2^19): quad reductions win up to 2^17 constraints with one or
+        // three proofs in flight (and still for a single proof beyond); quad accumulation only while the GPU is mostly idle
+        quad = max_entries() <= (1ull << 21) ? 4 : 1;
+        quad_acc = max_entries() <= (1ull << 17) ? 4 : 1;
+        if (const char *e = getenv("ZK_MSM_QUAD")) quad = atoi(e) ? 4 : 1;                                           // tuning aids
+        if (const char *e = getenv("ZK_MSM_QUAD_ACC")) quad_acc = atoi(e) ? 4 : 1;
     }
     uint64_t max_entries() const { return (uint64_t)n * W; }
     uint64_t max_segments() const { return max_entries() / seg + nb + 1; }
@@ -134,6 +142,9 @@ struct MsmWork {
     // the two halves: the bucket sort of this MSM's scalars, and accumulation + reduction driven by a sort view
     int enqueue_sort(const fe *scalars, const uint32_t *gather, uint32_t n, int canonical, hipStream_t st);
     int enqueue_reduce(const SortView &v, hipStream_t st, hipStream_t st_tail);
+    template <int Q> int launch_reduce(uint32_t K, uint32_t groups, hipStream_t st);
+    uint32_t tree_levels(uint32_t groups) const;
+    const uint32_t *cur_segoff = nullptr;       // segment offsets of the sort driving the current reduction
     SortView view() const { SortView v; v.sorted = sorted; v.off = off; v.segoff = segoff; v.seg = sh.seg; v.entries_bound = (uint32_t)((uint64_t)table_n * sh.W); return v; }
     // view for an MSM over scalars [offset, offset + n_dst) of THIS sort (its table has stride n_dst)
     SortView view_for(uint32_t offset, const uint32_t *pos = nullptr) const { SortView v = view(); v.remap_src = table_n; v.remap_offset = offset; v.remap_pos = pos; return v; }

@@ -243,14 +243,15 @@ k_msm_scan_add(uint32_t nbk, uint32_t ntiles, const uint32_t *__restrict__ tile_
     if (b == nbk) { off[nbk] = tile_a[ntiles]; segoff[nbk] = tile_b[ntiles]; }
 }
 
-// thread per segment; the segment -> bucket map is a binary search in segoff[] (nb + 1 entries)
-template <class C>
+// thread (Q = 1) or quad of lanes (Q = 4, see Curve::madd_q) per segment; the segment -> bucket map is a binary
+// search in segoff[] (nb + 1 entries)
+template <class C, int Q>
 __global__ void __launch_bounds__(64, C::WAVES_PER_SIMD)
 k_msm_accumulate(const typename C::Affine *__restrict__ table, const uint32_t *__restrict__ sorted,
                  const uint32_t *__restrict__ off, const uint32_t *__restrict__ segoff, uint32_t nb, uint32_t seg,
                  uint32_t remap_src, uint32_t remap_offset, const uint32_t *__restrict__ remap_pos, uint32_t n_dst,
                  typename C::XYZZ *__restrict__ segsum) {
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x, s = gt / Q, ql = gt % Q;
     const uint32_t nseg = segoff[nb];
     if (s >= nseg) return;
     uint32_t lo = 0, hi = nb;                                  // largest b with segoff[b] <= s
@@ -269,74 +270,77 @@ k_msm_accumulate(const typename C::Affine *__restrict__ table, const uint32_t *_
         }
         typename C::Affine q = table[idx];
         if (p >> 31) q = C::neg(q);
-        acc = C::madd(acc, q);
+        acc = C::template maddQ<Q>(acc, q, ql);
     }
-    segsum[s] = acc;
+    if (ql == 0) segsum[s] = acc;
 }
 
-// thread per bucket: sum its segment sums (serial; buckets over MSM_HEAVY segments are queued)
-template <class C>
+// thread / quad per bucket: sum its segment sums (serial; buckets over MSM_HEAVY segments are queued)
+template <class C, int Q>
 __global__ void __launch_bounds__(64, C::WAVES_PER_SIMD)
 k_msm_bucket_finalize(const typename C::XYZZ *__restrict__ segsum, const uint32_t *__restrict__ segoff,
                       uint32_t nb, typename C::XYZZ *__restrict__ bucket,
                       uint32_t *__restrict__ heavy_list, uint32_t *__restrict__ heavy_count) {
-    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x, b = gt / Q, ql = gt % Q;
     if (b >= nb) return;
     uint32_t s0 = segoff[b], s1 = segoff[b + 1];
-    if (s1 - s0 > MSM_HEAVY) { heavy_list[atomicAdd(heavy_count, 1u)] = b; return; }
+    if (s1 - s0 > MSM_HEAVY) { if (ql == 0) heavy_list[atomicAdd(heavy_count, 1u)] = b; return; }
     typename C::XYZZ acc = C::infinity();
-    for (uint32_t s = s0; s < s1; s++) acc = C::add(acc, segsum[s]);
-    bucket[b] = acc;
+    for (uint32_t s = s0; s < s1; s++) acc = C::template addQ<Q>(acc, segsum[s], ql);
+    if (ql == 0) bucket[b] = acc;
 }
 
-// workgroups walk the heavy list; 128 threads stride over the bucket's segments, then an LDS tree.
+// workgroups walk the heavy list; 128 threads / quads stride over the bucket's segments, then an LDS tree.
 // LDS holds 64 points (the upper half parks, the lower half adds) to stay inside 64 KiB for G2.
-template <class C>
-__global__ void __launch_bounds__(128)
+template <class C, int Q>
+__global__ void __launch_bounds__(128 * Q)
 k_msm_heavy(const typename C::XYZZ *__restrict__ segsum, const uint32_t *__restrict__ segoff,
             const uint32_t *__restrict__ heavy_list, const uint32_t *__restrict__ heavy_count,
             typename C::XYZZ *__restrict__ bucket) {
     __shared__ typename C::XYZZ sh[64];
-    const uint32_t nheavy = *heavy_count;
+    const uint32_t nheavy = *heavy_count, lt = threadIdx.x / Q, ql = threadIdx.x % Q;
     for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
         const uint32_t b = heavy_list[h], s0 = segoff[b], s1 = segoff[b + 1];
         typename C::XYZZ acc = C::infinity();
-        for (uint32_t s = s0 + threadIdx.x; s < s1; s += blockDim.x) acc = C::add(acc, segsum[s]);
+        for (uint32_t s = s0 + lt; s < s1; s += 128) acc = C::template addQ<Q>(acc, segsum[s], ql);
         for (uint32_t half = 64; half > 0; half >>= 1) {
-            if (threadIdx.x >= half && threadIdx.x < 2 * half) sh[threadIdx.x - half] = acc;
+            if (lt >= half && lt < 2 * half && ql == 0) sh[lt - half] = acc;
             __syncthreads();
-            if (threadIdx.x < half) acc = C::add(acc, sh[threadIdx.x]);
+            if (lt < half) acc = C::template addQ<Q>(acc, sh[lt], ql);
             __syncthreads();
         }
         if (threadIdx.x == 0) bucket[b] = acc;
     }
 }
 
-// thread per group of K consecutive buckets:  sum_j (g*K + j + 1) * B_{g*K+j}
-template <class C>
+// thread / quad per group of K consecutive buckets:  sum_j (g*K + j + 1) * B_{g*K+j}
+template <class C, int Q>
 __global__ void __launch_bounds__(64, C::WAVES_PER_SIMD)
 k_msm_group_reduce(const typename C::XYZZ *__restrict__ bucket, uint32_t nb, uint32_t K,
                    typename C::XYZZ *__restrict__ partial) {
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x, g = gt / Q, ql = gt % Q;
     if (g >= nb / K) return;
     const typename C::XYZZ *B = bucket + (size_t)g * K;
     typename C::XYZZ run = C::infinity(), acc = C::infinity();
-    for (uint32_t j = K; j-- > 0;) { run = C::add(run, B[j]); acc = C::add(acc, run); }
-    if (g) acc = C::add(acc, C::mul_small(run, g * K));
-    partial[g] = acc;
+    for (uint32_t j = K; j-- > 0;) { run = C::template addQ<Q>(run, B[j], ql); acc = C::template addQ<Q>(acc, run, ql); }
+    if (g) acc = C::template addQ<Q>(acc, C::template mul_smallQ<Q>(run, g * K, ql), ql);
+    if (ql == 0) partial[g] = acc;
 }
 
-// out[blockIdx] = sum of in[blockIdx*256 .. +256) (bounded by count): LDS tree, upper half parks
-template <class C>
+// out[blockIdx] = sum of in[blockIdx*T .. +T) (bounded by count), T = msm_tree_fan(Q) logical threads of Q lanes:
+// LDS tree, upper half parks
+template <class C, int Q>
 __global__ void __launch_bounds__(MSM_TREE)
 k_msm_tree_sum(const typename C::XYZZ *__restrict__ in, uint32_t count, typename C::XYZZ *__restrict__ out) {
-    __shared__ typename C::XYZZ sh[MSM_TREE / 2];
-    const uint32_t i = blockIdx.x * MSM_TREE + threadIdx.x;
+    constexpr uint32_t T = MSM_TREE / Q;
+    __shared__ typename C::XYZZ sh[T / 2];
+    const uint32_t lt = threadIdx.x / Q, ql = threadIdx.x % Q;
+    const uint32_t i = blockIdx.x * T + lt;
     typename C::XYZZ acc = i < count ? in[i] : C::infinity();
-    for (uint32_t half = MSM_TREE / 2; half > 0; half >>= 1) {
-        if (threadIdx.x >= half && threadIdx.x < 2 * half) sh[threadIdx.x - half] = acc;
+    for (uint32_t half = T / 2; half > 0; half >>= 1) {
+        if (lt >= half && lt < 2 * half && ql == 0) sh[lt - half] = acc;
         __syncthreads();
-        if (threadIdx.x < half) acc = C::add(acc, sh[threadIdx.x]);
+        if (lt < half) acc = C::template addQ<Q>(acc, sh[lt], ql);
         __syncthreads();
     }
     if (threadIdx.x == 0) out[blockIdx.x] = acc;
@@ -370,7 +374,7 @@ int MsmWork<C>::alloc(uint32_t n, uint32_t c, typename C::Affine *shared_table, 
     ZK_HIP(hipMalloc(&segsum, sizeof(typename C::XYZZ) * sh.max_segments()));
     ZK_HIP(hipMalloc(&bucket, sizeof(typename C::XYZZ) * sh.nb));
     ZK_HIP(hipMalloc(&partial_a, sizeof(typename C::XYZZ) * (groups + 1)));
-    ZK_HIP(hipMalloc(&partial_b, sizeof(typename C::XYZZ) * (zk_div_up(groups, MSM_TREE) + 1)));
+    ZK_HIP(hipMalloc(&partial_b, sizeof(typename C::XYZZ) * (zk_div_up(groups, MSM_TREE / sh.quad) + 1)));
     ZK_HIP(hipHostMalloc(&host_result, sizeof(typename C::XYZZ), hipHostMallocDefault));
     ZK_HIP(hipEventCreate(&ev_acc0)); ZK_HIP(hipEventCreate(&ev_acc1));
     return ZK_OK;
@@ -417,6 +421,34 @@ int MsmWork<C>::enqueue_sort(const fe *scalars, const uint32_t *gather, uint32_t
     return ZK_OK;
 }
 
+// number of tree-sum launches that take `groups` partials to one point (ping-pong partial_a -> partial_b -> ...)
+template <class C>
+uint32_t MsmWork<C>::tree_levels(uint32_t groups) const {
+    uint32_t levels = 0, count = groups;
+    do { count = zk_div_up(count, MSM_TREE / sh.quad); levels++; } while (count > 1);
+    return levels;
+}
+
+// bucket reduction with Q lanes per logical thread
+template <class C>
+template <int Q>
+int MsmWork<C>::launch_reduce(uint32_t K, uint32_t groups, hipStream_t st) {
+    const uint32_t nb = sh.nb;
+    ZK_LAUNCH((k_msm_bucket_finalize<C, Q>), zk_div_up((uint64_t)nb * Q, 64), 64, st, (const typename C::XYZZ *)segsum, (const uint32_t *)cur_segoff, nb, bucket, heavy_list, heavy_count);
+    ZK_LAUNCH_SYNC((k_msm_heavy<C, Q>), MSM_HEAVY_GRID, 128 * Q, st, (const typename C::XYZZ *)segsum, (const uint32_t *)cur_segoff,
+                   (const uint32_t *)heavy_list, (const uint32_t *)heavy_count, bucket);
+    ZK_LAUNCH((k_msm_group_reduce<C, Q>), zk_div_up((uint64_t)groups * Q, 64), 64, st, (const typename C::XYZZ *)bucket, nb, K, partial_a);
+    typename C::XYZZ *cur = partial_a, *nxt = partial_b;
+    uint32_t count = groups;
+    do {
+        uint32_t outc = zk_div_up(count, MSM_TREE / Q);
+        ZK_LAUNCH_SYNC((k_msm_tree_sum<C, Q>), outc, MSM_TREE, st, (const typename C::XYZZ *)cur, count, nxt);
+        typename C::XYZZ *t = cur; cur = nxt; nxt = t;
+        count = outc;
+    } while (count > 1);
+    return ZK_OK;
+}
+
 template <class C>
 int MsmWork<C>::enqueue_reduce(const SortView &v, hipStream_t st, hipStream_t st_tail) {
     if (!v.sorted || v.seg != sh.seg) return ZK_ERR_ARG;        // a borrowed sort must have this MSM's shape
@@ -427,22 +459,18 @@ int MsmWork<C>::enqueue_reduce(const SortView &v, hipStream_t st, hipStream_t st
     const uint64_t max_seg = (uint64_t)v.entries_bound / seg + nb + 1;
     if (max_seg > sh.max_segments()) return ZK_ERR_ARG;
     ZK_HIP(hipEventRecord(ev_acc0, st));
-    ZK_LAUNCH(k_msm_accumulate<C>, zk_div_up(max_seg, 64), 64, st, (const typename C::Affine *)table, v.sorted, v.off, v.segoff,
-              nb, seg, v.remap_src, v.remap_offset, v.remap_pos, table_n, segsum);
+    if (sh.quad_acc == 4)
+        ZK_LAUNCH((k_msm_accumulate<C, 4>), zk_div_up(max_seg * 4, 64), 64, st, (const typename C::Affine *)table, v.sorted, v.off, v.segoff,
+                  nb, seg, v.remap_src, v.remap_offset, v.remap_pos, table_n, segsum);
+    else
+        ZK_LAUNCH((k_msm_accumulate<C, 1>), zk_div_up(max_seg, 64), 64, st, (const typename C::Affine *)table, v.sorted, v.off, v.segoff,
+                  nb, seg, v.remap_src, v.remap_offset, v.remap_pos, table_n, segsum);
     ZK_HIP(hipEventRecord(ev_acc1, st));
     if (st_tail != st) { ZK_HIP(hipStreamWaitEvent(st_tail, ev_acc1, 0)); st = st_tail; }
-    ZK_LAUNCH(k_msm_bucket_finalize<C>, zk_div_up(nb, 64), 64, st, (const typename C::XYZZ *)segsum, v.segoff, nb, bucket, heavy_list, heavy_count);
-    ZK_LAUNCH_SYNC(k_msm_heavy<C>, MSM_HEAVY_GRID, 128, st, (const typename C::XYZZ *)segsum, v.segoff,
-                   (const uint32_t *)heavy_list, (const uint32_t *)heavy_count, bucket);
-    ZK_LAUNCH(k_msm_group_reduce<C>, zk_div_up(groups, 64), 64, st, (const typename C::XYZZ *)bucket, nb, K, partial_a);
-    typename C::XYZZ *cur = partial_a, *nxt = partial_b;
-    uint32_t count = groups;
-    do {
-        uint32_t outc = zk_div_up(count, MSM_TREE);
-        ZK_LAUNCH_SYNC(k_msm_tree_sum<C>, outc, MSM_TREE, st, (const typename C::XYZZ *)cur, count, nxt);
-        typename C::XYZZ *t = cur; cur = nxt; nxt = t;
-        count = outc;
-    } while (count > 1);
+    cur_segoff = v.segoff;
+    const int rc = sh.quad == 4 ? launch_reduce<4>(K, groups, st) : launch_reduce<1>(K, groups, st);
+    if (rc != ZK_OK) return rc;
+    typename C::XYZZ *cur = (tree_levels(groups) & 1) ? partial_b : partial_a;
     ZK_HIP(hipGetLastError());
     ZK_HIP(hipMemcpyAsync(host_result, cur, sizeof(typename C::XYZZ), hipMemcpyDeviceToHost, st));
     return ZK_OK;

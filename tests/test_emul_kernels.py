@@ -58,6 +58,18 @@ def test_msm_heavy_bucket(zk, oracle):
     assert np.array_equal(zk.msm(bases, s, c=6), oracle.msm(bases, s))
 
 
+@pytest.mark.parametrize("quad,quad_acc", [("0", "0"), ("1", "0"), ("0", "1")])
+def test_msm_lane_layouts(zk, oracle, monkeypatch, quad, quad_acc):
+    """small MSMs default to four lanes per logical thread (Curve::*_q); the one-lane kernels of the big sizes and the
+    mixed layouts must index the same way (ZK_MSM_QUAD / ZK_MSM_QUAD_ACC override the size rule)"""
+    monkeypatch.setenv("ZK_MSM_QUAD", quad); monkeypatch.setenv("ZK_MSM_QUAD_ACC", quad_acc)
+    n = 700
+    s = F.fr_to_mont([1] * 300 + rand_scalars(n - 300, 8, zeros_every=9))
+    for g2 in (False, True):
+        bases = oracle.batch_mul(F.fr_to_mont(rand_scalars(n, 21)), g2=g2)
+        assert np.array_equal(zk.msm(bases, s, g2=g2, c=5), oracle.msm(bases, s, g2=g2))
+
+
 def test_msm_all_cancel(zk, oracle):
     """P and -P with equal scalars, and P + P: exceptional cases of the mixed addition"""
     pts = oracle.batch_mul(F.fr_to_mont([5, 5, 9]))

@@ -79,6 +79,26 @@ def test_msm_exceptional_cases(hip, oracle):
     assert (hip.msm(bases, F.fr_to_mont([3, 3, 0, 0]), c=3) == 0).all()
 
 
+@pytest.mark.parametrize("quad,quad_acc", [("1", "1"), ("1", "0"), ("0", "0")], ids=["quad", "quad-tails", "one-lane"])
+@pytest.mark.parametrize("g2", [False, True], ids=["G1", "G2"])
+def test_msm_lane_layouts_and_segment_level_exceptions(hip, oracle, monkeypatch, g2, quad, quad_acc):
+    """Both lane layouts of the accumulation / reduction kernels (four cooperating lanes per logical thread for small
+    MSMs, one for large ones) on inputs whose SEGMENT sums collide: 16 copies of P under one scalar (8-entry segments ->
+    8P + 8P, the doubling branch of the XYZZ addition), then 8 x P and 8 x -P (8P + -8P = infinity), plus ordinary data."""
+    monkeypatch.setenv("ZK_MSM_QUAD", quad); monkeypatch.setenv("ZK_MSM_QUAD_ACC", quad_acc)
+    pts = oracle.batch_mul(F.fr_to_mont([5, 9]), g2=g2)
+    neg = pts[1].copy()
+    k = 8 if g2 else 4                                     # limbs (u64) of one coordinate
+    ycoords = F.fq_from_mont(neg[k:2 * k].reshape(-1, 4))
+    neg[k:2 * k] = F.fq_to_mont([(-v) % F.FQ for v in ycoords]).reshape(-1)
+    rest = tiled_bases(oracle, 600, g2=g2, distinct=256)
+    bases = np.concatenate([np.tile(pts[0], (16, 1)), np.tile(pts[1], (8, 1)), np.tile(neg, (8, 1)), rest])
+    sc = [12345] * 16 + [777] * 16 + rand_scalars(600, 17, ones_every=6, zeros_every=11)
+    s = F.fr_to_mont(sc)
+    for c in (0, 5, 11):
+        assert np.array_equal(hip.msm(bases, s, g2=g2, c=c), oracle.msm(bases, s, g2=g2))
+
+
 def test_msm_full_size_properties(hip, oracle):
     """2^20 points: result is invariant under a permutation of the (base, scalar) pairs and equals the
     oracle on the same data (the oracle takes a few seconds at this size with 16 threads)."""
