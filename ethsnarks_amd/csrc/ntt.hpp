@@ -36,11 +36,14 @@ static ZK_HD uint32_t bitrev32(uint32_t v, uint32_t bits) {
 //   src of pass 0   = bitrev(global index)      (ncol = 1, s0 = 0)
 // pre[]  (nullable) multiplies input element with natural index i by pre[i]  (coset shift g^i)
 // post[] (nullable) multiplies output element i by post[i]                   (1/m, g^-i/m, ...)
+// blockIdx.y selects one of several equal-size vectors laid out `batch_stride` elements apart (the A, B and C
+// polynomials of the witness map are transformed by one launch per pass)
 __global__ void __launch_bounds__(NTT_THREADS)
 k_ntt_pass(const fe *__restrict__ in, fe *__restrict__ out, const fe *__restrict__ tw,
            uint32_t logm, uint32_t s0, uint32_t k, uint32_t logc, int bitrev_load,
-           const fe *__restrict__ pre, const fe *__restrict__ post) {
+           const fe *__restrict__ pre, const fe *__restrict__ post, uint32_t batch_stride) {
     __shared__ uint32_t sh[8][NTT_TILE];
+    in += (size_t)blockIdx.y * batch_stride; out += (size_t)blockIdx.y * batch_stride;
     const uint32_t tile = 1u << (k + logc), ncol = 1u << logc;
     const uint32_t nlb = (1u << s0) >> logc;                  // column groups per high index
     const uint32_t lb = blockIdx.x & (nlb - 1), h = blockIdx.x / nlb;
@@ -158,29 +161,30 @@ static inline int ntt_tables_create(NttTables &t, uint32_t logm, hipStream_t st)
 }
 
 // out <- transform(in); in and out must be different buffers (pass 0 permutes).  `pre`/`post` as in k_ntt_pass.
+// batch > 1: `batch` vectors, `stride` elements apart in both in and out, one launch per pass.
 static inline int ntt_run(const NttTables &t, const fe *in, fe *out, bool inverse,
-                          const fe *pre, const fe *post, hipStream_t st) {
+                          const fe *pre, const fe *post, hipStream_t st, uint32_t batch = 1, uint32_t stride = 0) {
     const uint32_t logm = t.logm, m = 1u << logm;
     const fe *tw = inverse ? t.tw_inv : t.tw_fwd;
     if (logm == 0) {   // size-1 transform is the identity (times scaling)
         uint32_t k0 = 0;
-        ZK_LAUNCH_SYNC(k_ntt_pass, 1, NTT_THREADS, st, in, out, tw, logm, 0u, k0, 0u, 1, pre, post);
+        ZK_LAUNCH_SYNC(k_ntt_pass, dim3(1, batch), NTT_THREADS, st, in, out, tw, logm, 0u, k0, 0u, 1, pre, post, stride);
         return ZK_OK;
     }
     const uint32_t k0 = logm < (uint32_t)NTT_TILE_LOG ? logm : NTT_TILE_LOG;
     uint32_t rem = logm - k0;
     const uint32_t kmax = NTT_TILE_LOG - NTT_MIN_LOGC;
     uint32_t npass = (rem + kmax - 1) / kmax;
-    ZK_LAUNCH_SYNC(k_ntt_pass, m >> k0, NTT_THREADS, st, in, out, tw, logm, 0u, k0, 0u, 1, pre,
-                   rem == 0 ? post : (const fe *)nullptr);
+    ZK_LAUNCH_SYNC(k_ntt_pass, dim3(m >> k0, batch), NTT_THREADS, st, in, out, tw, logm, 0u, k0, 0u, 1, pre,
+                   rem == 0 ? post : (const fe *)nullptr, stride);
     uint32_t s0 = k0;
     while (rem) {
         uint32_t k = (rem + npass - 1) / npass;
         uint32_t logc = NTT_TILE_LOG - k;
         if (logc > s0) logc = s0;
         rem -= k; npass--;
-        ZK_LAUNCH_SYNC(k_ntt_pass, m >> (k + logc), NTT_THREADS, st, (const fe *)out, out, tw, logm, s0, k, logc, 0,
-                       (const fe *)nullptr, rem == 0 ? post : (const fe *)nullptr);
+        ZK_LAUNCH_SYNC(k_ntt_pass, dim3(m >> (k + logc), batch), NTT_THREADS, st, (const fe *)out, out, tw, logm, s0, k, logc, 0,
+                       (const fe *)nullptr, rem == 0 ? post : (const fe *)nullptr, stride);
         s0 += k;
     }
     ZK_HIP(hipGetLastError());

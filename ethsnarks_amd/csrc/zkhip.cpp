@@ -359,7 +359,7 @@ struct zk_ctx {
                ev_l0 = nullptr, ev_l1 = nullptr, ev_h1 = nullptr, ev_h0 = nullptr;
     ~zk_ctx() {
         hipSetDevice(device);
-        void *dev[] = {d_w, d_a, d_b, d_c, d_t};
+        void *dev[] = {d_w, d_a, d_t};                       // d_b, d_c live inside d_a's allocation
         for (void *p : dev) if (p) hipFree(p);
         if (h_w) hipHostFree(h_w);
         if (h_tail) hipHostFree(h_tail);
@@ -442,8 +442,8 @@ static int ctx_build(zk_ctx *c, const zk_pk *pk, const zk_csr *A, const zk_csr *
     ZK_TRY(c->mB.alloc(c->rB.n(), c->cfg.multi_exp_c, t->tB, t->share_B ? &c->mW.sh : nullptr));
     ZK_TRY(c->cA.upload(A, V)); ZK_TRY(c->cB.upload(B, V)); ZK_TRY(c->cC.upload(C, V));
     ZK_HIP(hipMalloc(&c->d_w, 32 * (size_t)(V + 1)));
-    ZK_HIP(hipMalloc(&c->d_a, 32 * (size_t)m)); ZK_HIP(hipMalloc(&c->d_b, 32 * (size_t)m));
-    ZK_HIP(hipMalloc(&c->d_c, 32 * (size_t)m)); ZK_HIP(hipMalloc(&c->d_t, 32 * (size_t)m));
+    ZK_HIP(hipMalloc(&c->d_a, 3 * 32 * (size_t)m)); c->d_b = c->d_a + m; c->d_c = c->d_a + 2 * (size_t)m;   // A | B | C: one batched NTT launch per pass
+    ZK_HIP(hipMalloc(&c->d_t, 3 * 32 * (size_t)m));
     ZK_HIP(hipHostMalloc(&c->h_w, 32 * (size_t)(V + 1), hipHostMallocDefault));
     ZK_HIP(hipHostMalloc(&c->h_tail, 32, hipHostMallocDefault));
     // s_main carries the critical chain (H polynomial -> H-query): highest priority; the A-, B-, L-query
@@ -495,18 +495,14 @@ extern "C" void zk_ctx_destroy(zk_ctx *ctx) { delete ctx; }
 static int enqueue_compute_h(zk_ctx *c) {
     hipStream_t st = c->s_main;
     const uint32_t m = c->m;
-    ZK_HIP(hipMemsetAsync(c->d_a, 0, 32 * (size_t)m, st));
-    ZK_HIP(hipMemsetAsync(c->d_b, 0, 32 * (size_t)m, st));
-    ZK_HIP(hipMemsetAsync(c->d_c, 0, 32 * (size_t)m, st));
+    ZK_HIP(hipMemsetAsync(c->d_a, 0, 3 * 32 * (size_t)m, st));       // d_a | d_b | d_c
     ZK_TRY(c->cA.enqueue(c->d_w, c->d_a, st));
     ZK_TRY(c->cB.enqueue(c->d_w, c->d_b, st));
     ZK_TRY(c->cC.enqueue(c->d_w, c->d_c, st));
     ZK_LAUNCH(k_set_input_rows, zk_div_up(c->nIn + 1, 64), 64, st, c->d_a, (const fe *)c->d_w, c->nC, c->nIn);
-    fe *polys[3] = {c->d_a, c->d_b, c->d_c};
-    for (fe *p : polys) {
-        ZK_TRY(ntt_run(c->tab, p, c->d_t, true, nullptr, c->tab.inv_then_coset, st));   // iFFT, then x g^i (cosetFFT pre-scale)
-        ZK_TRY(ntt_run(c->tab, c->d_t, p, false, nullptr, nullptr, st));               // FFT -> evaluations on the coset
-    }
+    // the three polynomials go through each pass together (blockIdx.y): 3 x fewer, 3 x larger launches
+    ZK_TRY(ntt_run(c->tab, c->d_a, c->d_t, true, nullptr, c->tab.inv_then_coset, st, 3, m));   // iFFT, then x g^i (cosetFFT pre-scale)
+    ZK_TRY(ntt_run(c->tab, c->d_t, c->d_a, false, nullptr, nullptr, st, 3, m));               // FFT -> evaluations on the coset
     ZK_LAUNCH(k_pointwise_h, zk_div_up(m, 256), 256, st, c->d_a, (const fe *)c->d_b, (const fe *)c->d_c, c->tab.zinv, m);
     ZK_TRY(ntt_run(c->tab, c->d_a, c->d_t, true, nullptr, c->tab.icoset, st));          // icosetFFT
     ZK_HIP(hipMemcpyAsync(c->h_tail, c->d_t + (m - 1), 32, hipMemcpyDeviceToHost, st));

@@ -48,18 +48,20 @@ inline void trampoline() { (*g_body)(); g_cur->done = true; }
 template <class Body>
 void launch(bool needs_sync, dim3 grid, dim3 block, Body body) {
     if (!needs_sync) {
-        for (unsigned bx = 0; bx < grid.x; bx++)
-            for (unsigned tx = 0; tx < block.x; tx++) {
-                threadIdx = dim3(tx); blockIdx = dim3(bx); blockDim = block; gridDim = grid;
-                body();
-            }
+        for (unsigned by = 0; by < grid.y; by++)
+            for (unsigned bx = 0; bx < grid.x; bx++)
+                for (unsigned tx = 0; tx < block.x; tx++) {
+                    threadIdx = dim3(tx); blockIdx = dim3(bx, by); blockDim = block; gridDim = grid;
+                    body();
+                }
         return;
     }
     std::function<void()> fn = body;
     g_body = &fn;
     if (g_fibers.size() < block.x) g_fibers.resize(block.x);
     if (g_stacks.size() < (size_t)block.x * FIBER_STACK) g_stacks.resize((size_t)block.x * FIBER_STACK);
-    for (unsigned bx = 0; bx < grid.x; bx++) {
+    for (unsigned bxy = 0; bxy < grid.x * grid.y; bxy++) {
+        const unsigned bx = bxy % grid.x, by = bxy / grid.x;
         for (unsigned tx = 0; tx < block.x; tx++) {
             Fiber &f = g_fibers[tx];
             getcontext(&f.ctx);
@@ -75,7 +77,7 @@ void launch(bool needs_sync, dim3 grid, dim3 block, Body body) {
             for (unsigned tx = 0; tx < block.x; tx++) {
                 Fiber &f = g_fibers[tx];
                 if (f.done) continue;
-                threadIdx = dim3(tx); blockIdx = dim3(bx); blockDim = block; gridDim = grid;
+                threadIdx = dim3(tx); blockIdx = dim3(bx, by); blockDim = block; gridDim = grid;
                 g_cur = &f;
                 swapcontext(&g_sched, &f.ctx);
                 if (!f.done) any = true;
