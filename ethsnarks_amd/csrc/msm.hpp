@@ -22,6 +22,9 @@
 //   5 k_msm_bucket_finalize / k_msm_heavy   segment sums -> bucket sums
 //   6 k_msm_group_reduce   sum_b (b+1) * B_b over groups of buckets (running sums + small offset multiple)
 //   7 k_msm_tree_sum    LDS tree over the group partials -> the MSM result (one XYZZ point)
+// Kernels 4-7 are templated on the lanes per logical thread: <C, 1> for machine-filling sizes, <C, 4> (four lanes
+// share one point operation, Curve::add_q / dbl_q / madd_q in bn254.hpp) where a proof is a chain of dependent
+// additions rather than a throughput problem (MsmShape::quad / quad_acc).
 // Zero scalars produce no entries; scalar 1 (and any repeated value) lands in one bucket whose entries
 // are cut into segments, so 0/1-heavy witnesses (the *_with_mixed_addition fast paths of the reference)
 // stay load-balanced without special cases; buckets with very many segments go to a workgroup reducer.
