@@ -273,6 +273,40 @@ struct Field {
         if constexpr (P::is_fq) fips::reduce8_fq2(r.l); else fips::reduce8_fr2(r.l);
         return r;
     }
+    // a*b + c*d + e*f + g*h with one reduction: (16p^2 + Rp)/R < 4.03p, two folds by 2p (an Fq2 dot product of two terms)
+    template <int I>
+    static __device__ __forceinline__ void fips_low4(uint64_t &lo, uint32_t &hi, uint32_t (&m)[8], const fe &a, const fe &b, const fe &c, const fe &d,
+                                                     const fe &e, const fe &f, const fe &g, const fe &h) {
+        col_ab<I + 1, 0, I>(lo, hi, a, b); col_ab<I + 1, 0, I>(lo, hi, c, d); col_ab<I + 1, 0, I>(lo, hi, e, f); col_ab<I + 1, 0, I>(lo, hi, g, h);
+        if constexpr (I > 0) col_mp<I, 0, I>(lo, hi, m);
+        m[I] = (uint32_t)lo * P::inv;
+        fips::mac1_vs(lo, hi, m[I], P::p(0));
+        lo = (lo >> 32) | ((uint64_t)hi << 32); hi = 0;
+    }
+    template <int I>
+    static __device__ __forceinline__ void fips_high4(uint64_t &lo, uint32_t &hi, const uint32_t (&m)[8], uint32_t (&t)[8], const fe &a, const fe &b, const fe &c, const fe &d,
+                                                      const fe &e, const fe &f, const fe &g, const fe &h) {
+        col_ab<15 - I, I - 7, I>(lo, hi, a, b); col_ab<15 - I, I - 7, I>(lo, hi, c, d); col_ab<15 - I, I - 7, I>(lo, hi, e, f); col_ab<15 - I, I - 7, I>(lo, hi, g, h);
+        col_mp<15 - I, I - 7, I>(lo, hi, m);
+        t[I - 8] = (uint32_t)lo;
+        lo = (lo >> 32) | ((uint64_t)hi << 32); hi = 0;
+    }
+    static __device__ __forceinline__ fe lmul4(const fe &a, const fe &b, const fe &c, const fe &d, const fe &e, const fe &f, const fe &g, const fe &h) {
+        uint64_t lo = 0; uint32_t hi = 0;
+        uint32_t m[8], t[8];
+#define ZK_L4(I) fips_low4<I>(lo, hi, m, a, b, c, d, e, f, g, h)
+#define ZK_H4(I) fips_high4<I>(lo, hi, m, t, a, b, c, d, e, f, g, h)
+        ZK_L4(0); ZK_L4(1); ZK_L4(2); ZK_L4(3); ZK_L4(4); ZK_L4(5); ZK_L4(6); ZK_L4(7);
+        ZK_H4(8); ZK_H4(9); ZK_H4(10); ZK_H4(11); ZK_H4(12); ZK_H4(13); ZK_H4(14);
+#undef ZK_L4
+#undef ZK_H4
+        t[7] = (uint32_t)lo;
+        fe r;
+#pragma unroll
+        for (int i = 0; i < 8; i++) r.l[i] = t[i];
+        if constexpr (P::is_fq) { fips::reduce8_fq2(r.l); fips::reduce8_fq2(r.l); } else { fips::reduce8_fr2(r.l); fips::reduce8_fr2(r.l); }
+        return r;
+    }
 #else
     static ZK_HD fe mul(const fe &a, const fe &b) { return mul_cios(a, b); }
 #endif
@@ -304,6 +338,9 @@ struct Field {
 #else
     static ZK_HD fe lmul(const fe &a, const fe &b) { return mul(a, b); }
     static ZK_HD fe lmul2(const fe &a, const fe &b, const fe &c, const fe &d) { return add(mul(a, b), mul(c, d)); }
+    static ZK_HD fe lmul4(const fe &a, const fe &b, const fe &c, const fe &d, const fe &e, const fe &f, const fe &g, const fe &h) {
+        return add(add(mul(a, b), mul(c, d)), add(mul(e, f), mul(g, h)));
+    }
     static ZK_HD fe ladd(const fe &a, const fe &b) { return add(a, b); }
     static ZK_HD fe lsub(const fe &a, const fe &b) { return sub(a, b); }
     static ZK_HD bool lis_zero(const fe &a) { return is_zero(a); }
@@ -393,6 +430,13 @@ struct Fq2 {
         r.c1 = Fq::lmul2(a.c0, b.c1, a.c1, b.c0);
         return r;
     }
+    // a*b + c*d in Fq2, one reduction per component
+    static ZK_HD fe2 lmul2(const fe2 &a, const fe2 &b, const fe2 &c, const fe2 &d) {
+        fe2 r;
+        r.c0 = Fq::lmul4(a.c0, b.c0, a.c1, Fq::lneg(b.c1), c.c0, d.c0, c.c1, Fq::lneg(d.c1));
+        r.c1 = Fq::lmul4(a.c0, b.c1, a.c1, b.c0, c.c0, d.c1, c.c1, d.c0);
+        return r;
+    }
     static ZK_HD fe2 lsqr(const fe2 &a) {
         fe p = Fq::lmul(a.c0, a.c1);
         fe2 r; r.c0 = Fq::lmul(Fq::ladd(a.c0, a.c1), Fq::lsub(a.c0, a.c1)); r.c1 = Fq::ladd(p, p); return r;
@@ -437,7 +481,7 @@ struct Curve {
         E xx = F::lsqr(p.x), M = F::ladd(F::ldbl(xx), xx);
         XYZZ r;
         r.X = F::lsub(F::lsqr(M), F::ldbl(S));
-        r.Y = F::lsub(F::lmul(M, F::lsub(S, r.X)), F::lmul(W, p.y));
+        r.Y = F::lmul2(M, F::lsub(S, r.X), W, F::lneg(p.y));           // M (S - X3) - W y: one reduction
         r.ZZ = V; r.ZZZ = W;
         return r;
     }
@@ -448,7 +492,7 @@ struct Curve {
         E xx = F::lsqr(p.X), M = F::ladd(F::ldbl(xx), xx);
         XYZZ r;
         r.X = F::lsub(F::lsqr(M), F::ldbl(S));
-        r.Y = F::lsub(F::lmul(M, F::lsub(S, r.X)), F::lmul(W, p.Y));
+        r.Y = F::lmul2(M, F::lsub(S, r.X), W, F::lneg(p.Y));
         r.ZZ = F::lmul(V, p.ZZ); r.ZZZ = F::lmul(W, p.ZZZ);
         return r;
     }
@@ -465,7 +509,7 @@ struct Curve {
         E PP = F::lsqr(Pd), PPP = F::lmul(Pd, PP), Q = F::lmul(p.X, PP);
         XYZZ r;
         r.X = F::lsub(F::lsub(F::lsqr(R), PPP), F::ldbl(Q));
-        r.Y = F::lsub(F::lmul(R, F::lsub(Q, r.X)), F::lmul(p.Y, PPP));
+        r.Y = F::lmul2(R, F::lsub(Q, r.X), F::lneg(p.Y), PPP);        // R (Q - X3) - Y1 PPP: one reduction
         r.ZZ = F::lmul(p.ZZ, PP); r.ZZZ = F::lmul(p.ZZZ, PPP);
         return r;
     }
@@ -483,7 +527,7 @@ struct Curve {
         E PP = F::lsqr(Pd), PPP = F::lmul(Pd, PP), Q = F::lmul(U1, PP);
         XYZZ r;
         r.X = F::lsub(F::lsub(F::lsqr(R), PPP), F::ldbl(Q));
-        r.Y = F::lsub(F::lmul(R, F::lsub(Q, r.X)), F::lmul(S1, PPP));
+        r.Y = F::lmul2(R, F::lsub(Q, r.X), F::lneg(S1), PPP);
         r.ZZ = F::lmul(F::lmul(p.ZZ, q.ZZ), PP); r.ZZZ = F::lmul(F::lmul(p.ZZZ, q.ZZZ), PPP);
         return r;
     }
