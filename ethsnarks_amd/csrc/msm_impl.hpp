@@ -260,17 +260,44 @@ k_msm_accumulate(const typename C::Affine *__restrict__ table, const uint32_t *_
     uint32_t begin = off[b] + (s - segoff[b]) * seg, end = begin + seg;
     if (end > off[b + 1]) end = off[b + 1];
     typename C::XYZZ acc = C::infinity();
-    for (uint32_t e = begin; e < end; e++) {
-        uint32_t p = sorted[e], idx = p & 0x7fffffffu;
+    // software pipeline over the segment: the sorted entry (and, where the registers allow it -- G1 --, the table point)
+    // of iteration e + 1 is requested before the mixed addition of iteration e, so the two dependent gather latencies
+    // hide behind ~3000 VALU instructions instead of stalling the wave between additions
+    constexpr bool PREFETCH_POINT = sizeof(typename C::Affine) <= 64;
+    auto entry_index = [&](uint32_t p) -> uint32_t {             // table index of an entry, or 0xffffffff when it is not this query's
+        uint32_t idx = p & 0x7fffffffu;
         if (remap_src) {                                        // entry of another query's sort: (window, scalar) -> own table
             const uint32_t w = idx / remap_src, i = idx - w * remap_src;
             const uint32_t k = remap_pos ? remap_pos[i] : i - remap_offset;     // unsigned wrap / 0xffffffff = absent
-            if (k >= n_dst) continue;
+            if (k >= n_dst) return 0xffffffffu;
             idx = w * n_dst + k;
         }
-        typename C::Affine q = table[idx];
+        return idx;
+    };
+    uint32_t p_next = begin < end ? sorted[begin] : 0u;
+    typename C::Affine q_next = C::aff_infinity();
+    if constexpr (PREFETCH_POINT) {
+        if (begin < end) { const uint32_t idx = entry_index(p_next); if (idx != 0xffffffffu) q_next = table[idx]; }
+    }
+    for (uint32_t e = begin; e < end; e++) {
+        const uint32_t p = p_next;
+        typename C::Affine q;
+        if constexpr (PREFETCH_POINT) {
+            q = q_next;
+            if (e + 1 < end) {
+                p_next = sorted[e + 1];
+                const uint32_t idx = entry_index(p_next);
+                q_next = C::aff_infinity();
+                if (idx != 0xffffffffu) q_next = table[idx];
+            }
+        } else {
+            if (e + 1 < end) p_next = sorted[e + 1];
+            const uint32_t idx = entry_index(p);
+            if (idx == 0xffffffffu) continue;
+            q = table[idx];
+        }
         if (p >> 31) q = C::neg(q);
-        acc = C::template maddQ<Q>(acc, q, ql);
+        acc = C::template maddQ<Q>(acc, q, ql);                 // an absent entry is the point at infinity: acc unchanged
     }
     if (ql == 0) segsum[s] = acc;
 }
