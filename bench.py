@@ -33,14 +33,14 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 MAD_LANE_OPS_PER_CLK_CU = 43.4  # measured v_mad_u64_u32 rate, tools/microbench (profiles/r01_microbench.txt)
-FQ_MUL_MADS = 136               # 8x8 product + 8x8 reduction + 8 quotient digits (CIOS, 32-bit limbs)
+MADS_PER_G2_MADD = 6 * 400 + 2 * 272 + 656   # = 3600, see the valu block below
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--logm", type=int, default=20, help="domain size 2^logm (nC = 2^logm - 2)")
     ap.add_argument("--mode", choices=["shard", "replicas"], default="replicas")
     ap.add_argument("--workload", choices=["chain", "merkle29", "mimc11"], default="chain",
@@ -180,7 +180,9 @@ def main():
         W = 254 // (args.multi_exp_c or P_pick_c(nB_local)) + 1
         alg_bytes = 160.0 * nB_local                                   # 128 B G2 base + 32 B scalar per pair
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-        fq_muls = 28.0 * nB_local * W                                  # G2 mixed add = 8 M + 2 S over Fq2 = 28 Fq products
+        # multiplies (v_mad_u64_u32 lane-ops) of one G2 mixed addition as the kernel computes it: 6 Fq2 products x (4 x 64 + 2 x 72)
+        # + 2 Fq2 squarings x (2 x 136) + one two-term Fq2 dot product x 2 x (4 x 64 + 72)   (bn254.hpp: Fq2::lmul / lsqr / lmul2)
+        mads = float(MADS_PER_G2_MADD) * nB_local * W
         bytes_per_proof = proof_bytes(r1cs, pk, m)
         out = {
             "metric": "groth16_proofs_per_sec", "value": round(value, 4), "unit": "proofs/s",
@@ -192,17 +194,19 @@ def main():
             "config": {"workload": workload,
                        "parallelism": ("msm-shard%d+allgather640B" % world) if shard else ("replicas%d" % world if world > 1 else "1gpu"),
                        "multi_exp_c": args.multi_exp_c or P_pick_c(nB_local), "witness": "host buffer, H2D inside the timed region", "inflight": max(1, args.inflight)},
-            "roofline": {"kernel": "k_msm_accumulate<G2> (B-query bucket accumulation)", "bound": "hbm",
+            "roofline": {"kernel": "k_msm_accumulate<G2, 1> (B-query bucket accumulation)", "bound": "hbm",
                          "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": pmc_traffic("k_msm_accumulate<G2>", world if shard else 1),
+                         "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": pmc_traffic("k_msm_accumulate<G2, 1>", world if shard else 1),
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(kern_ms, 4),
                          "note": "VALU-integer bound kernel (no dense contraction, no MFMA): see valu. traffic > algorithmic bytes by design: "
                                  "each base is read through its W window multiples (msm.hpp), trading HBM bytes for 16x fewer bucket reductions"},
-            "valu": {"kernel": "k_msm_accumulate<G2>", "unit": "G Fq-mul/s", "achieved": round(fq_muls / (kern_ms * 1e-3) / 1e9, 3) if kern_ms > 0 else 0.0,
-                     "peak": round(MAD_LANE_OPS_PER_CLK_CU * 256 * 2.4 / FQ_MUL_MADS, 1),
-                     "peak_basis": "measured v_mad_u64_u32 issue rate x 256 CU x 2.4 GHz / 136 mads per Montgomery product",
-                     "issue_slot_bound": round(256 * 128 * 2.4 / (136 * 2.47 + 155), 1),
-                     "issue_slot_basis": "all VALU issue slots at 2.4 GHz spent on the product's own mix: 136 multiplies at 2.47 slots + 155 single-slot instructions"},
+            "valu": {"kernel": "k_msm_accumulate<G2, 1>", "unit": "T mad/s (v_mad_u64_u32 lane-ops)",
+                     "achieved": round(mads / (kern_ms * 1e-3) / 1e12, 3) if kern_ms > 0 else 0.0,
+                     "peak": round(MAD_LANE_OPS_PER_CLK_CU * 256 * 2.4e9 / 1e12, 2),
+                     "frac": round(mads / (kern_ms * 1e-3) / (MAD_LANE_OPS_PER_CLK_CU * 256 * 2.4e9), 4) if kern_ms > 0 else 0.0,
+                     "peak_basis": "measured v_mad_u64_u32 issue rate (43.4 lane-ops/clk/CU, profiles/r01_microbench.txt) x 256 CU x 2.4 GHz; "
+                                   "the multiplies are 2/3 of the kernel's VALU issue slots, the rest are carry/fold/select instructions",
+                     "mads_per_mixed_addition": MADS_PER_G2_MADD},
             "proof_hbm": {"algorithmic_bytes_per_proof": bytes_per_proof,
                           "achieved_GBps": round(bytes_per_proof * value / 1e9, 3),
                           "frac_of_peak": round(bytes_per_proof * value / 1e9 / (world * HBM_PEAK_GBPS), 6)},
