@@ -226,6 +226,38 @@ def test_async_submit_collect_two_contexts(hip, oracle):
         assert hip.proof_to_json(c.prove_combine(part), wm[1:2]) == expect
 
 
+def test_concurrent_provers_one_context_per_thread(hip, oracle):
+    """The reference's threading rule (ProverContext scratch is per prover, the key is shared read-only): four host
+    threads, each with its own context on the same key and different witnesses, prove at the same time; contexts are
+    created concurrently too (the device-table cache is shared between them)."""
+    import threading
+    r, _ = R.synthetic_chain((1 << 13) - 2, 1)
+    pk_o, _ = oracle.keygen(r, seed=21)
+    pk = hip.ProvingKey.from_parts(**pk_o.parts())
+    cases = []
+    for t in range(4):
+        _, w = R.synthetic_chain((1 << 13) - 2, 1, seed=1000 + t)      # same constraint system, different witness
+        wm = F.fr_to_mont(w)
+        cases.append((wm, oracle.prove(pk_o, r, wm)[0]))
+    results, errors = [None] * 4, []
+
+    def worker(t):
+        try:
+            ctx = hip.ProverContext(pk, r)
+            out = [hip.prove(ctx, cases[t][0]) for _ in range(5)]
+            ctx.close()
+            results[t] = out
+        except Exception as e:                                         # surfaced in the main thread below
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for th in threads: th.start()
+    for th in threads: th.join()
+    assert not errors, errors
+    for t in range(4):
+        assert results[t] == [cases[t][1]] * 5
+
+
 def test_config3_chain_2pow20_headline(hip, oracle):
     """BASELINE config 3 (the bench workload): 2^20-constraint chain, key from zk_keygen; the proof is
     byte-identical to the CPU oracle, and the 4-way base-range sharded path reproduces it"""
