@@ -88,9 +88,9 @@ typedef struct {
 typedef struct {
     float h2d_witness;
     float compute_h;           /* "Compute the polynomial H" */
-    float a_query, b_query, h_query, l_query;   /* GPU time of each multi-exponentiation */
+    float a_query, b_query, h_query, l_query;   /* "Compute the proof's A-query" ... "L-query": GPU time of each multi-exponentiation */
     float gpu_total;           /* first kernel to last copy */
-    float host_finish;         /* window Horner, final additions, affine conversion */
+    float host_finish;         /* "Compute the proof": final additions (tcc:533-540), affine conversion */
     float acc_a, acc_b, acc_h, acc_l;   /* k_msm_accumulate launch of each query, HIP events on its stream */
 } zk_timings;
 
