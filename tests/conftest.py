@@ -36,7 +36,7 @@ def emul():
     srcs = [os.path.join(ROOT, "ethsnarks_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "ethsnarks_amd", "csrc")) if f.endswith(("pp",))]
     srcs.append(os.path.join(ROOT, "tests", "emul", "hip_emul.h"))
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "emul"), "-s"])
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "emul"), "-s", "-j5"])
     return so
 
 
