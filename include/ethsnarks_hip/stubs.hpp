@@ -7,6 +7,8 @@
 //   ethsnarks::stub_genkeys_from_pb(pb, pk_file, vk_file)         src/stubs.hpp:16,  src/stubs.cpp:77-87
 //   ethsnarks::stub_prove_from_pb(pb, pk_raw)                     upstream wrapper, src/pinocchio/main.cpp:10,41
 //   ethsnarks::stub_main_prove<GadgetT>(prog, argc, argv)         CLI helper shaped like stub_main_genkeys, src/stubs.hpp:36-55
+//   ethsnarks::stub_genkeys<GadgetT>, stub_main_genkeys<GadgetT>  src/stubs.hpp:23-55
+//   ethsnarks::stub_main_verify(prog, argc, argv)                 src/stubs.hpp:12,  src/stubs.cpp:90-132
 //   ethsnarks::stub_verify(vk_json, proof_json)                   src/stubs.hpp:10,  src/stubs.cpp:16-33
 //   ethsnarks::stub_test_proof_verify(pb)                         src/stubs.hpp:14,  src/stubs.cpp:135-148 (context fully initialised)
 //
@@ -212,6 +214,49 @@ inline bool stub_test_proof_verify(ProtoboardT &pb) {
     const std::string proof = stub_prove_from_pb(pb, pk_tmp.c_str());
     std::remove(pk_tmp.c_str()); std::remove(vk_tmp.c_str());
     return stub_verify(vk.c_str(), proof.c_str());
+}
+
+// stub_genkeys<GadgetT> / stub_main_genkeys<GadgetT> (src/stubs.hpp:23-55): build the gadget's constraints on a fresh
+// protoboard and write the key pair; argv = {command, pk-output.raw, vk-output.json}; 0 on success, 1 otherwise
+template <class GadgetT>
+int stub_genkeys(const char *pk_file, const char *vk_file) {
+    ppT::init_public_params();
+    ProtoboardT pb;
+    GadgetT mod(pb, "module");
+    mod.generate_r1cs_constraints();
+    return stub_genkeys_from_pb(pb, pk_file, vk_file);
+}
+template <class GadgetT>
+int stub_main_genkeys(const char *prog_name, int argc, char **argv) {
+    if (argc < 3) {
+        std::cerr << "Usage: " << prog_name << " " << argv[0] << " <pk-output.raw> <vk-output.json>" << std::endl;
+        return 1;
+    }
+    if (stub_genkeys<GadgetT>(argv[1], argv[2]) != 0) {
+        std::cerr << "Error: failed to generate proving and verifying keys" << std::endl;
+        return 1;
+    }
+    return 0;
+}
+
+// stub_main_verify (src/stubs.cpp:90-132): argv = {command, vk.json, proof.json}; 0 verified, 1 usage / rejected,
+// 2 a file cannot be opened
+inline int stub_main_verify(const char *prog_name, int argc, const char **argv) {
+    if (argc < 3) {
+        std::cerr << "Usage: " << prog_name << " " << argv[0] << " <vk.json> <proof.json>" << std::endl;
+        return 1;
+    }
+    std::string text[2];
+    for (int i = 0; i < 2; i++) {
+        std::ifstream in(argv[1 + i], std::ios::binary);
+        if (!in) { std::cerr << "Error: cannot open " << argv[1 + i] << std::endl; return 2; }
+        text[i].assign(std::istreambuf_iterator<char>(in), std::istreambuf_iterator<char>());
+    }
+    bool ok = false;
+    try { ok = stub_verify(text[0].c_str(), text[1].c_str()); } catch (const std::exception &e) { std::cerr << "Error: " << e.what() << std::endl; }
+    if (ok) return 0;
+    std::cerr << "Error: failed to verify proof!" << std::endl;
+    return 1;
 }
 
 // stub_main_prove: argv helper shaped like stub_main_genkeys (src/stubs.hpp:36-55)

@@ -8,6 +8,7 @@
 //   frontend_test dump  <r1cs.json> <witness.json>     depth-29 Merkle membership circuit in r1cs2json / witness2json form
 //   frontend_test prove <pk.raw> <vk.json> <proof.json>   keygen + prove + verify of that circuit through the adapter (GPU)
 //   frontend_test roundtrip                            stub_test_proof_verify on the MiMC hash circuit (GPU)
+//   frontend_test verify_cli <vk.json> <proof.json>    stub_main_verify (host only): exit code 0 / 1 / 2 like the reference's
 #include "ethsnarks_hip/stubs.hpp"
 #include "ethsnarks_hip/gadgets.hpp"
 
@@ -146,6 +147,11 @@ int main(int argc, char **argv) {
             const bool ok = stub_verify(vk.c_str(), proof.c_str());
             std::cout << (ok ? "VERIFIED" : "REJECTED") << std::endl;
             return ok ? 0 : 1;
+        }
+        if (mode == "verify_cli") {                           // stub_main_verify's own argv convention: {command, vk, proof}
+            std::vector<const char *> av;
+            for (int i = 1; i < argc; i++) av.push_back(argv[i]);
+            return stub_main_verify("frontend_test", (int)av.size(), av.data());
         }
         if (mode == "roundtrip") {
             ProtoboardT pb;

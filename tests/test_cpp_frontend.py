@@ -58,6 +58,20 @@ def test_cpp_and_python_front_ends_build_the_same_circuit(exe, tmp_path):
         assert _rows(a) == _rows(b)
 
 
+def test_stub_main_verify_exit_codes(exe, tmp_path):
+    """stub_main_verify (src/stubs.cpp:90-132) on the reference's static triple: 0 verified, 1 rejected / usage, 2 unreadable"""
+    d = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_static_triple.json")))
+    vk, proof, bad = str(tmp_path / "vk.json"), str(tmp_path / "proof.json"), str(tmp_path / "bad.json")
+    json.dump(d["vk"], open(vk, "w")); json.dump(d["proof"], open(proof, "w"))
+    tampered = dict(d["proof"]); tampered["input"] = [hex(int(tampered["input"][0], 16) ^ 1)] + tampered["input"][1:]
+    json.dump(tampered, open(bad, "w"))
+    run = lambda *a: subprocess.run([exe, "verify_cli", *a], capture_output=True, text=True)
+    assert run(vk, proof).returncode == 0
+    r = run(vk, bad); assert r.returncode == 1 and "failed to verify" in r.stderr
+    r = run(vk, str(tmp_path / "missing.json")); assert r.returncode == 2 and "cannot open" in r.stderr
+    r = run(vk); assert r.returncode == 1 and "Usage" in r.stderr
+
+
 @pytest.mark.gpu
 def test_adapter_genkeys_prove_verify_matches_oracle(exe, oracle, tmp_path):
     pk, vk, pj = str(tmp_path / "pk.raw"), str(tmp_path / "vk.json"), str(tmp_path / "proof.json")
