@@ -176,7 +176,9 @@ struct Field {
     // gfx950 form: finely integrated product scanning.  Column k of a*b + m*p is summed into a 96-bit
     // accumulator (64-bit VGPR pair + 32-bit carry word): every partial product is ONE v_mad_u64_u32 whose
     // 64-bit addend is the accumulator itself, plus ONE v_addc_co_u32 that banks the carry-out the mad
-    // leaves in an SGPR pair.  hipcc cannot use that carry-out from C (it builds zero-extended addend pairs
+    // leaves in an SGPR pair.  The kernels built on it are bound by VALU issue: measured on MI355X the product
+    // costs the SUM of its instructions' issue times (v_mad_u64_u32 ~5.9 cycles per wave and SIMD, simple VALU
+    // ~2.4, tools/mulbench.cpp), multiplies and carry adds do not overlap.  hipcc cannot use that carry-out from C (it builds zero-extended addend pairs
     // with v_mov / v_lshl_add_u64 instead: 565 VALU instructions per product against ~330 here).
     // The modulus limbs ride in SGPRs (wave-uniform constants).  VALU-written SGPR carry -> VALU carry-in is
     // hardware-interlocked on gfx9 (the same pattern hipcc emits through VCC), so no s_nop is needed.
@@ -207,105 +209,79 @@ struct Field {
         if constexpr (N == 8) fips::mac8_vs(lo, hi, ZK_MP(0), ZK_MP(1), ZK_MP(2), ZK_MP(3), ZK_MP(4), ZK_MP(5), ZK_MP(6), ZK_MP(7));
 #undef ZK_MP
     }
-    template <int I>
-    static __device__ __forceinline__ void fips_low(uint64_t &lo, uint32_t &hi, uint32_t (&m)[8], const fe &a, const fe &b) {
-        col_ab<I + 1, 0, I>(lo, hi, a, b);                 // a_0 b_I + ... + a_I b_0
-        if constexpr (I > 0) col_mp<I, 0, I>(lo, hi, m);   // m_0 p_I + ... + m_{I-1} p_1
-        m[I] = (uint32_t)lo * P::inv;
-        fips::mac1_vs(lo, hi, m[I], P::p(0));              // low word of the column is now 0
-        lo = (lo >> 32) | ((uint64_t)hi << 32); hi = 0;
+    // Column scheme.  The column accumulator is (hi:lo) = a 64-bit VGPR pair + a 32-bit carry word.  The FIRST multiply-add
+    // of a column takes the previous column's upper 64 bits {lo.hi, hi} as its addend and SETS the carry word
+    // (fips::macN_*_set: write-only, early-clobber outputs), so moving on to the next column is one v_mov (lo.hi into the
+    // even register of the addend pair; gfx90a+ wants 64-bit operands even-aligned) instead of three (shift the pair, clear
+    // the carry word).  NP = number of a*b products summed before the single reduction (1: product, 2 / 4: dot products).
+    template <int N, int J0, int I>
+    static __device__ __forceinline__ void col_ab_set(uint64_t &lo, uint32_t &hi, uint64_t ad, const fe &a, const fe &b) {
+#define ZK_AB(k) a.l[J0 + k], b.l[I - J0 - k]
+        if constexpr (N == 1) fips::mac1_vv_set(lo, hi, ad, ZK_AB(0));
+        if constexpr (N == 2) fips::mac2_vv_set(lo, hi, ad, ZK_AB(0), ZK_AB(1));
+        if constexpr (N == 3) fips::mac3_vv_set(lo, hi, ad, ZK_AB(0), ZK_AB(1), ZK_AB(2));
+        if constexpr (N == 4) fips::mac4_vv_set(lo, hi, ad, ZK_AB(0), ZK_AB(1), ZK_AB(2), ZK_AB(3));
+        if constexpr (N == 5) fips::mac5_vv_set(lo, hi, ad, ZK_AB(0), ZK_AB(1), ZK_AB(2), ZK_AB(3), ZK_AB(4));
+        if constexpr (N == 6) fips::mac6_vv_set(lo, hi, ad, ZK_AB(0), ZK_AB(1), ZK_AB(2), ZK_AB(3), ZK_AB(4), ZK_AB(5));
+        if constexpr (N == 7) fips::mac7_vv_set(lo, hi, ad, ZK_AB(0), ZK_AB(1), ZK_AB(2), ZK_AB(3), ZK_AB(4), ZK_AB(5), ZK_AB(6));
+        if constexpr (N == 8) fips::mac8_vv_set(lo, hi, ad, ZK_AB(0), ZK_AB(1), ZK_AB(2), ZK_AB(3), ZK_AB(4), ZK_AB(5), ZK_AB(6), ZK_AB(7));
+#undef ZK_AB
     }
-    template <int I>
-    static __device__ __forceinline__ void fips_high(uint64_t &lo, uint32_t &hi, const uint32_t (&m)[8], uint32_t (&t)[8], const fe &a, const fe &b) {
-        col_ab<15 - I, I - 7, I>(lo, hi, a, b);            // a_{I-7} b_7 + ... + a_7 b_{I-7}
-        col_mp<15 - I, I - 7, I>(lo, hi, m);
-        t[I - 8] = (uint32_t)lo;
-        lo = (lo >> 32) | ((uint64_t)hi << 32); hi = 0;
-    }
-    template <bool REDUCE>
-    static __device__ __forceinline__ fe mul_fips(const fe &a, const fe &b) {
-        uint64_t lo = 0; uint32_t hi = 0;
+    // m_i = t_i * (-p^-1) mod 2^32 through the 64-bit multiplier: v_mad_u64_u32 issues faster than v_mul_lo_u32 on gfx950
+    static __device__ __forceinline__ uint32_t mont_m(uint32_t t0) { return fips::mullo_vs(t0, P::inv); }
+    static __device__ __forceinline__ uint64_t next_addend(uint64_t lo, uint32_t hi) { return (lo >> 32) | ((uint64_t)hi << 32); }
+    template <int NP, bool REDUCE>
+    static __device__ __forceinline__ fe mul_fips_n(const fe *const (&op)[2 * NP]) {
+        uint64_t lo, ad; uint32_t hi;
         uint32_t m[8], t[8];
-        fips_low<0>(lo, hi, m, a, b); fips_low<1>(lo, hi, m, a, b); fips_low<2>(lo, hi, m, a, b); fips_low<3>(lo, hi, m, a, b);
-        fips_low<4>(lo, hi, m, a, b); fips_low<5>(lo, hi, m, a, b); fips_low<6>(lo, hi, m, a, b); fips_low<7>(lo, hi, m, a, b);
-        fips_high<8>(lo, hi, m, t, a, b); fips_high<9>(lo, hi, m, t, a, b); fips_high<10>(lo, hi, m, t, a, b); fips_high<11>(lo, hi, m, t, a, b);
-        fips_high<12>(lo, hi, m, t, a, b); fips_high<13>(lo, hi, m, t, a, b); fips_high<14>(lo, hi, m, t, a, b);
-        t[7] = (uint32_t)lo;                               // column 15 is empty: just the carry of column 14
+        // column 0: one product per pair, no addend
+        fips::mul1_vv(lo, op[0]->l[0], op[1]->l[0]);
+        if constexpr (NP >= 2) fips::mac1_vv_sethi(lo, hi, op[2]->l[0], op[3]->l[0]);
+        if constexpr (NP >= 4) { fips::mac1_vv(lo, hi, op[4]->l[0], op[5]->l[0]); fips::mac1_vv(lo, hi, op[6]->l[0], op[7]->l[0]); }
+        m[0] = mont_m((uint32_t)lo);
+        if constexpr (NP == 1) fips::mac1_vs_sethi(lo, hi, m[0], P::p(0)); else fips::mac1_vs(lo, hi, m[0], P::p(0));
+        ad = next_addend(lo, hi);
+#define ZK_LOW(I) \
+        col_ab_set<I + 1, 0, I>(lo, hi, ad, *op[0], *op[1]);   /* a_0 b_I + ... + a_I b_0 */ \
+        if constexpr (NP >= 2) col_ab<I + 1, 0, I>(lo, hi, *op[2], *op[3]); \
+        if constexpr (NP >= 4) { col_ab<I + 1, 0, I>(lo, hi, *op[4], *op[5]); col_ab<I + 1, 0, I>(lo, hi, *op[6], *op[7]); } \
+        col_mp<I, 0, I>(lo, hi, m);                            /* m_0 p_I + ... + m_{I-1} p_1 */ \
+        m[I] = mont_m((uint32_t)lo); \
+        fips::mac1_vs(lo, hi, m[I], P::p(0));                  /* low word of the column is now 0 */ \
+        ad = next_addend(lo, hi);
+#define ZK_HIGH(I) \
+        col_ab_set<15 - I, I - 7, I>(lo, hi, ad, *op[0], *op[1]);   /* a_{I-7} b_7 + ... + a_7 b_{I-7} */ \
+        if constexpr (NP >= 2) col_ab<15 - I, I - 7, I>(lo, hi, *op[2], *op[3]); \
+        if constexpr (NP >= 4) { col_ab<15 - I, I - 7, I>(lo, hi, *op[4], *op[5]); col_ab<15 - I, I - 7, I>(lo, hi, *op[6], *op[7]); } \
+        col_mp<15 - I, I - 7, I>(lo, hi, m); \
+        t[I - 8] = (uint32_t)lo; \
+        ad = next_addend(lo, hi);
+        ZK_LOW(1) ZK_LOW(2) ZK_LOW(3) ZK_LOW(4) ZK_LOW(5) ZK_LOW(6) ZK_LOW(7)
+        ZK_HIGH(8) ZK_HIGH(9) ZK_HIGH(10) ZK_HIGH(11) ZK_HIGH(12) ZK_HIGH(13) ZK_HIGH(14)
+#undef ZK_LOW
+#undef ZK_HIGH
+        t[7] = (uint32_t)ad;                               // column 15 is empty: just the carry of column 14
         fe r;
 #pragma unroll
         for (int i = 0; i < 8; i++) r.l[i] = t[i];
-        if constexpr (REDUCE) return reduce_once(r);
-        else return r;                                     // a, b < 2p  =>  result < 2p (p < 2^254): see "loose domain" below
+        if constexpr (NP == 1) { if constexpr (REDUCE) return reduce_once(r); else return r; }   // a, b < 2p  =>  result < 2p (p < 2^254): see "loose domain" below
+        if constexpr (NP >= 2) { if constexpr (P::is_fq) fips::reduce8_fq2(r.l); else fips::reduce8_fr2(r.l); }    // (8p^2 + Rp)/R < 2.51p: one fold by 2p
+        if constexpr (NP >= 4) { if constexpr (P::is_fq) fips::reduce8_fq2(r.l); else fips::reduce8_fr2(r.l); }    // (16p^2 + Rp)/R < 4.03p: two folds
+        return r;
     }
+    template <bool REDUCE>
+    static __device__ __forceinline__ fe mul_fips(const fe &a, const fe &b) { const fe *const op[2] = {&a, &b}; return mul_fips_n<1, REDUCE>(op); }
     static __device__ __forceinline__ fe mul(const fe &a, const fe &b) { return mul_fips<true>(a, b); }
     // a*b + c*d with ONE Montgomery reduction: both products are summed into the same columns before the m*p terms
     // (2 x 64 + 72 multiplies instead of 2 x 136, and no separate modular addition).  Loose inputs (< 2p) give
     // (8p^2 + Rp)/R < 2.51p, so one fold by 2p brings the result back into [0, 2p).  This is what an Fq2 product is
     // made of: c0 = a0 b0 + a1 (-b1), c1 = a0 b1 + a1 b0.
-    template <int I>
-    static __device__ __forceinline__ void fips_low2(uint64_t &lo, uint32_t &hi, uint32_t (&m)[8], const fe &a, const fe &b, const fe &c, const fe &d) {
-        col_ab<I + 1, 0, I>(lo, hi, a, b);
-        col_ab<I + 1, 0, I>(lo, hi, c, d);
-        if constexpr (I > 0) col_mp<I, 0, I>(lo, hi, m);
-        m[I] = (uint32_t)lo * P::inv;
-        fips::mac1_vs(lo, hi, m[I], P::p(0));
-        lo = (lo >> 32) | ((uint64_t)hi << 32); hi = 0;
-    }
-    template <int I>
-    static __device__ __forceinline__ void fips_high2(uint64_t &lo, uint32_t &hi, const uint32_t (&m)[8], uint32_t (&t)[8], const fe &a, const fe &b, const fe &c, const fe &d) {
-        col_ab<15 - I, I - 7, I>(lo, hi, a, b);
-        col_ab<15 - I, I - 7, I>(lo, hi, c, d);
-        col_mp<15 - I, I - 7, I>(lo, hi, m);
-        t[I - 8] = (uint32_t)lo;
-        lo = (lo >> 32) | ((uint64_t)hi << 32); hi = 0;
-    }
     static __device__ __forceinline__ fe lmul2(const fe &a, const fe &b, const fe &c, const fe &d) {
-        uint64_t lo = 0; uint32_t hi = 0;
-        uint32_t m[8], t[8];
-        fips_low2<0>(lo, hi, m, a, b, c, d); fips_low2<1>(lo, hi, m, a, b, c, d); fips_low2<2>(lo, hi, m, a, b, c, d); fips_low2<3>(lo, hi, m, a, b, c, d);
-        fips_low2<4>(lo, hi, m, a, b, c, d); fips_low2<5>(lo, hi, m, a, b, c, d); fips_low2<6>(lo, hi, m, a, b, c, d); fips_low2<7>(lo, hi, m, a, b, c, d);
-        fips_high2<8>(lo, hi, m, t, a, b, c, d); fips_high2<9>(lo, hi, m, t, a, b, c, d); fips_high2<10>(lo, hi, m, t, a, b, c, d); fips_high2<11>(lo, hi, m, t, a, b, c, d);
-        fips_high2<12>(lo, hi, m, t, a, b, c, d); fips_high2<13>(lo, hi, m, t, a, b, c, d); fips_high2<14>(lo, hi, m, t, a, b, c, d);
-        t[7] = (uint32_t)lo;
-        fe r;
-#pragma unroll
-        for (int i = 0; i < 8; i++) r.l[i] = t[i];
-        if constexpr (P::is_fq) fips::reduce8_fq2(r.l); else fips::reduce8_fr2(r.l);
-        return r;
+        const fe *const op[4] = {&a, &b, &c, &d}; return mul_fips_n<2, false>(op);
     }
     // a*b + c*d + e*f + g*h with one reduction: (16p^2 + Rp)/R < 4.03p, two folds by 2p (an Fq2 dot product of two terms)
-    template <int I>
-    static __device__ __forceinline__ void fips_low4(uint64_t &lo, uint32_t &hi, uint32_t (&m)[8], const fe &a, const fe &b, const fe &c, const fe &d,
-                                                     const fe &e, const fe &f, const fe &g, const fe &h) {
-        col_ab<I + 1, 0, I>(lo, hi, a, b); col_ab<I + 1, 0, I>(lo, hi, c, d); col_ab<I + 1, 0, I>(lo, hi, e, f); col_ab<I + 1, 0, I>(lo, hi, g, h);
-        if constexpr (I > 0) col_mp<I, 0, I>(lo, hi, m);
-        m[I] = (uint32_t)lo * P::inv;
-        fips::mac1_vs(lo, hi, m[I], P::p(0));
-        lo = (lo >> 32) | ((uint64_t)hi << 32); hi = 0;
-    }
-    template <int I>
-    static __device__ __forceinline__ void fips_high4(uint64_t &lo, uint32_t &hi, const uint32_t (&m)[8], uint32_t (&t)[8], const fe &a, const fe &b, const fe &c, const fe &d,
-                                                      const fe &e, const fe &f, const fe &g, const fe &h) {
-        col_ab<15 - I, I - 7, I>(lo, hi, a, b); col_ab<15 - I, I - 7, I>(lo, hi, c, d); col_ab<15 - I, I - 7, I>(lo, hi, e, f); col_ab<15 - I, I - 7, I>(lo, hi, g, h);
-        col_mp<15 - I, I - 7, I>(lo, hi, m);
-        t[I - 8] = (uint32_t)lo;
-        lo = (lo >> 32) | ((uint64_t)hi << 32); hi = 0;
-    }
     static __device__ __forceinline__ fe lmul4(const fe &a, const fe &b, const fe &c, const fe &d, const fe &e, const fe &f, const fe &g, const fe &h) {
-        uint64_t lo = 0; uint32_t hi = 0;
-        uint32_t m[8], t[8];
-#define ZK_L4(I) fips_low4<I>(lo, hi, m, a, b, c, d, e, f, g, h)
-#define ZK_H4(I) fips_high4<I>(lo, hi, m, t, a, b, c, d, e, f, g, h)
-        ZK_L4(0); ZK_L4(1); ZK_L4(2); ZK_L4(3); ZK_L4(4); ZK_L4(5); ZK_L4(6); ZK_L4(7);
-        ZK_H4(8); ZK_H4(9); ZK_H4(10); ZK_H4(11); ZK_H4(12); ZK_H4(13); ZK_H4(14);
-#undef ZK_L4
-#undef ZK_H4
-        t[7] = (uint32_t)lo;
-        fe r;
-#pragma unroll
-        for (int i = 0; i < 8; i++) r.l[i] = t[i];
-        if constexpr (P::is_fq) { fips::reduce8_fq2(r.l); fips::reduce8_fq2(r.l); } else { fips::reduce8_fr2(r.l); fips::reduce8_fr2(r.l); }
-        return r;
+        const fe *const op[8] = {&a, &b, &c, &d, &e, &f, &g, &h}; return mul_fips_n<4, false>(op);
     }
 #else
     static ZK_HD fe mul(const fe &a, const fe &b) { return mul_cios(a, b); }
