@@ -17,16 +17,16 @@
 //   1 k_sort_count / k_sort_colscan / k_sort_binscan / k_sort_partition   scalar -> signed c-bit digits ->
 //                       entries partitioned into <= 256 coarse bucket bins (LDS ranking, no global atomics)
 //   2 k_sort_fine       one workgroup per coarse bin: LDS histogram + in-L2 scatter by bucket
-//   3 k_msm_scan_*      exclusive scan: fixed-length *segments* per bucket
-//   4 k_msm_accumulate  one thread per segment: XYZZ mixed additions            <- dominant kernel
-//   5 k_msm_bucket_finalize / k_msm_heavy   segment sums -> bucket sums
-//   6 k_msm_group_reduce   sum_b (b+1) * B_b over groups of buckets (running sums + small offset multiple)
-//   7 k_msm_tree_sum    LDS tree over the group partials -> the MSM result (one XYZZ point)
-// Kernels 4-7 are templated on the lanes per logical thread: <C, 1> for machine-filling sizes, <C, 4> (four lanes
+//   3 k_msm_accumulate  one thread per *chunk* of consecutive sorted entries (equal length for every thread, bucket
+//                       boundaries crossed inside the loop): XYZZ mixed additions   <- dominant kernel
+//   4 k_msm_bucket_finalize / k_msm_heavy   chunk pieces -> bucket sums
+//   5 k_msm_group_reduce   sum_b (b+1) * B_b over groups of buckets (running sums + small offset multiple)
+//   6 k_msm_tree_sum    LDS tree over the group partials -> the MSM result (one XYZZ point)
+// Kernels 3-6 are templated on the lanes per logical thread: <C, 1> for machine-filling sizes, <C, 4> (four lanes
 // share one point operation, Curve::add_q / dbl_q / madd_q in bn254.hpp) where a proof is a chain of dependent
 // additions rather than a throughput problem (MsmShape::quad / quad_acc).
 // Zero scalars produce no entries; scalar 1 (and any repeated value) lands in one bucket whose entries
-// are cut into segments, so 0/1-heavy witnesses (the *_with_mixed_addition fast paths of the reference)
+// are cut into chunk pieces, so 0/1-heavy witnesses (the *_with_mixed_addition fast paths of the reference)
 // stay load-balanced without special cases; buckets with very many segments go to a workgroup reducer.
 #pragma once
 #include "bn254.hpp"
@@ -37,8 +37,8 @@ namespace zk {
 
 constexpr uint32_t MSM_SEG_MIN = 32;      // entries per accumulation thread (lower bound) when the entries fill the machine
 constexpr uint32_t MSM_SEG_MIN_SMALL = 8; // ... and for MSMs of <= 2^23 entries, whose time is the serial chain per thread, not throughput
-constexpr uint32_t MSM_SEG_PER_BUCKET = 16;   // target segments per bucket (sets the segment length)
-constexpr uint32_t MSM_HEAVY = 64;        // buckets with more segments than this are reduced by a workgroup
+constexpr uint32_t MSM_SEG_MAX = 64;      // ... upper bound: above it the entries are dealt in more than one round of the machine
+constexpr uint32_t MSM_HEAVY = 64;        // buckets with more chunk pieces than this are reduced by a workgroup
 constexpr uint32_t MSM_GROUP = 8;         // buckets per running-sum thread (ZK_MSM_GROUP overrides: tuning aid)
 constexpr uint32_t MSM_GROUP_SMALL = 4;   // ... for <= 2^15 buckets (latency-bound sizes; measured at 2^12 / 2^15 / 2^18, tools/dev_small_sweep.sh)
 inline uint32_t msm_group(uint32_t nb) {
@@ -74,8 +74,37 @@ struct SortShape {
     }
 };
 
+// Entries per accumulation thread.  The sorted entry list is cut into chunks of ONE length, whatever the bucket
+// boundaries (a thread flushes its running sum when it crosses one), so every lane of every wave does the same number
+// of mixed additions; the length is the smallest one that deals all entries in whole rounds of the machine
+// (`slots` = accumulation threads resident at once), clamped to [seg_min, seg_max].  Device and host agree on it
+// through this one function of the entry count, which only the device knows (off[nb]).
+struct ChunkRule {
+    uint32_t slots = 1, seg_min = MSM_SEG_MIN, seg_max = MSM_SEG_MAX;
+    ZK_HD uint32_t len(uint32_t total) const {
+        if ((uint64_t)seg_min * slots >= total) return seg_min;
+        const uint64_t per_round = (uint64_t)seg_max * slots;
+        const uint64_t rounds = (total + per_round - 1) / per_round, lanes = rounds * slots;
+        const uint32_t seg = (uint32_t)((total + lanes - 1) / lanes);
+        return seg < seg_min ? seg_min : seg;
+    }
+    // most chunks any entry count <= entries_bound can give
+    uint64_t max_chunks(uint64_t entries_bound) const { return entries_bound / seg_max + slots + 1; }
+};
+// threads of one accumulation launch that the device holds at once (waves/SIMD x 4 SIMDs x CUs x 64 lanes)
+inline uint32_t msm_machine_threads(uint32_t waves_per_simd) {
+#ifdef ZK_EMUL
+    return 32 * waves_per_simd;                 // the emulator has no machine to fill: small, so that tests see several rounds
+#else
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    return (uint32_t)cus * 4u * waves_per_simd * 64u;
+#endif
+}
+
 struct MsmShape {
-    uint32_t n = 0, c = 0, W = 0, nb = 0, seg = MSM_SEG_MIN;
+    uint32_t n = 0, c = 0, W = 0, nb = 0;
+    ChunkRule chunk;
     uint32_t quad = 1;      // lanes per logical thread in the bucket-reduction kernels: 1, or 4 (Curve::*_q) for latency-bound sizes
     uint32_t quad_acc = 1;  // ... and in the accumulation kernel (only while 4 lanes per segment still fit the machine at once)
     // largest window with >= 32 entries per bucket on average (n * W entries over 2^(c-1) buckets)
@@ -89,27 +118,30 @@ struct MsmShape {
         if (c < 2) c = 2;
         if (c > 20) c = 20;
         W = 254 / c + 1; nb = 1u << (c - 1);
-        seg = max_entries() <= (1ull << 23) ? MSM_SEG_MIN_SMALL : MSM_SEG_MIN;
-        if (const char *e = getenv("ZK_SEG_MIN")) { int v = atoi(e); if (v >= 4) seg = (uint32_t)v; }                // tuning aid
-        uint32_t spb = MSM_SEG_PER_BUCKET;
-        if (const char *e = getenv("ZK_SEG_PER_BUCKET")) { int v = atoi(e); if (v > 0) spb = (uint32_t)v; }   // tuning aid
-        while (seg < 4096 && (uint64_t)seg * nb * spb < max_entries()) seg <<= 1;
         // measured (tools/dev_small_sweep.sh, domains 2^13 .. 2^19): quad reductions win up to 2^17 constraints with one or
         // three proofs in flight (and still for a single proof beyond); quad accumulation only while the GPU is mostly idle
         quad = max_entries() <= (1ull << 21) ? 4 : 1;
         quad_acc = max_entries() <= (1ull << 17) ? 4 : 1;
         if (const char *e = getenv("ZK_MSM_QUAD")) quad = atoi(e) ? 4 : 1;                                           // tuning aids
         if (const char *e = getenv("ZK_MSM_QUAD_ACC")) quad_acc = atoi(e) ? 4 : 1;
+        chunk.seg_min = max_entries() <= (1ull << 23) ? MSM_SEG_MIN_SMALL : MSM_SEG_MIN;
+        chunk.seg_max = MSM_SEG_MAX;
+        if (const char *e = getenv("ZK_SEG_MIN")) { int v = atoi(e); if (v >= 4) chunk.seg_min = (uint32_t)v; }    // tuning aids
+        if (const char *e = getenv("ZK_SEG_MAX")) { int v = atoi(e); if (v >= 4) chunk.seg_max = (uint32_t)v; }
+        if (chunk.seg_max < chunk.seg_min) chunk.seg_max = chunk.seg_min;
     }
+    // the slot count depends on the curve (registers per thread): MsmWork<C>::alloc completes the rule
+    void set_slots(uint32_t waves_per_simd) { chunk.slots = msm_machine_threads(waves_per_simd) / quad_acc; if (!chunk.slots) chunk.slots = 1; }
     uint64_t max_entries() const { return (uint64_t)n * W; }
-    uint64_t max_segments() const { return max_entries() / seg + nb + 1; }
+    uint64_t max_chunks() const { return chunk.max_chunks(max_entries()); }
+    uint64_t max_pieces() const { return max_chunks() + nb + 1; }       // a chunk starts one piece, every bucket boundary one more
 };
 
 // what k_msm_accumulate needs from a finished bucket sort; `remap_src` != 0 means the entries index another
 // MSM's table ([w][remap_src] layout, scalar i) and this MSM covers scalars [remap_offset, remap_offset + n)
 struct SortView {
-    const uint32_t *sorted = nullptr, *off = nullptr, *segoff = nullptr;
-    uint32_t seg = 0, entries_bound = 0;            // entries_bound: upper bound of sorted entries (n_src * W)
+    const uint32_t *sorted = nullptr, *off = nullptr;   // off[b] = entries before bucket b, off[nb] = all entries
+    uint32_t nb = 0, entries_bound = 0;             // entries_bound: upper bound of sorted entries (n_src * W)
     uint32_t remap_src = 0, remap_offset = 0;
     const uint32_t *remap_pos = nullptr;            // optional scalar index -> own base index (0xffffffff: absent); else i - remap_offset
 };
@@ -123,8 +155,8 @@ struct MsmWork {
     bool owns_table = true;                     // false: the table belongs to a DeviceTables entry shared by several contexts
     uint2 *pairs = nullptr;                     // pass-1 output of the bucket sort: (payload, bucket)
     uint32_t *counts = nullptr, *bin_total = nullptr, *bin_base = nullptr;
-    uint32_t *hist = nullptr, *off = nullptr, *segoff = nullptr, *sorted = nullptr;
-    uint32_t *heavy_list = nullptr, *heavy_count = nullptr, *tile_a = nullptr, *tile_b = nullptr;
+    uint32_t *off = nullptr, *sorted = nullptr;
+    uint32_t *heavy_list = nullptr, *heavy_count = nullptr;
     typename C::XYZZ *segsum = nullptr, *bucket = nullptr, *partial_a = nullptr, *partial_b = nullptr;
     typename C::XYZZ *host_result = nullptr;    // pinned, 1 entry
     hipEvent_t ev_acc0 = nullptr, ev_acc1 = nullptr;   // bracket k_msm_accumulate (the dominant kernel) on its stream
@@ -147,8 +179,8 @@ struct MsmWork {
     int enqueue_reduce(const SortView &v, hipStream_t st, hipStream_t st_tail);
     template <int Q> int launch_reduce(uint32_t K, uint32_t groups, hipStream_t st);
     uint32_t tree_levels(uint32_t groups) const;
-    const uint32_t *cur_segoff = nullptr;       // segment offsets of the sort driving the current reduction
-    SortView view() const { SortView v; v.sorted = sorted; v.off = off; v.segoff = segoff; v.seg = sh.seg; v.entries_bound = (uint32_t)((uint64_t)table_n * sh.W); return v; }
+    const uint32_t *cur_off = nullptr;          // bucket offsets of the sort driving the current reduction
+    SortView view() const { SortView v; v.sorted = sorted; v.off = off; v.nb = sh.nb; v.entries_bound = (uint32_t)((uint64_t)table_n * sh.W); return v; }
     // view for an MSM over scalars [offset, offset + n_dst) of THIS sort (its table has stride n_dst)
     SortView view_for(uint32_t offset, const uint32_t *pos = nullptr) const { SortView v = view(); v.remap_src = table_n; v.remap_offset = offset; v.remap_pos = pos; return v; }
     typename C::XYZZ finish() const { return C::canon(*host_result); }   // device values are loose ([0, 2p)): normalise once

@@ -30,7 +30,7 @@ k_msm_precompute(const typename C::Affine *__restrict__ bases, uint32_t n, uint3
 // workgroup re-derives its digits and writes (bucket, payload) pairs at LDS-ranked positions
 // (k_sort_partition): runs of ~64 consecutive pairs per bin per workgroup.  Pass 2 gives every coarse bin
 // to one workgroup (k_sort_fine): LDS histogram of its <= 2^15/CB fine buckets, local scan, and an in-L2
-// scatter of the payloads.  It also emits the bucket histogram and offsets.  payload = table index | sign.
+// scatter of the payloads.  It also emits the bucket offsets off[0..nb].  payload = table index | sign.
 // signed c-bit digit of window w (carry in/out); returns magnitude (0 = no entry) and sign
 static ZK_D uint32_t msm_digit(const fe &s, uint32_t w, uint32_t c, uint32_t &carry, uint32_t &neg) {
     const uint32_t nb = 1u << (c - 1), full = 1u << c;
@@ -134,13 +134,13 @@ k_sort_partition(const fe *__restrict__ scalars, const uint32_t *__restrict__ ga
     }
 }
 
-// pass 2: one workgroup per coarse bin sorts its region by fine bucket; emits hist[], off[] and sorted[].
+// pass 2: one workgroup per coarse bin sorts its region by fine bucket; emits off[] (nb + 1 entries) and sorted[].
 // 1024 threads per workgroup: the pass is latency-bound (two sweeps over ~60 K pairs), so it wants every wave
 // slot of the CU it runs on.
 template <class C>
 __global__ void __launch_bounds__(SORT_FINE_THREADS)
 k_sort_fine(const uint2 *__restrict__ pairs, const uint32_t *__restrict__ bin_base, SortShape ss,
-            uint32_t *__restrict__ hist, uint32_t *__restrict__ off, uint32_t *__restrict__ sorted) {
+            uint32_t *__restrict__ off, uint32_t *__restrict__ sorted) {
     __shared__ uint32_t cnt[SORT_MAX_FB], cur[SORT_MAX_FB], sh[SORT_FINE_THREADS];
     const uint32_t bin = blockIdx.x, r0 = bin_base[bin], r1 = bin_base[bin + 1], t = threadIdx.x, T = blockDim.x;
     const uint32_t fmask = ss.fb - 1;
@@ -163,9 +163,10 @@ k_sort_fine(const uint2 *__restrict__ pairs, const uint32_t *__restrict__ bin_ba
     uint32_t ex = sh[t] - sum;
     for (uint32_t k = k0; k < k1; k++) {
         const uint32_t b = bin * ss.fb + k;
-        hist[b] = cnt[k]; off[b] = r0 + ex; cur[k] = r0 + ex;
+        off[b] = r0 + ex; cur[k] = r0 + ex;
         ex += cnt[k];
     }
+    if (bin + 1 == gridDim.x && t == 0) off[(bin + 1) * ss.fb] = r1;   // off[nb] = all entries
     __syncthreads();
     for (uint32_t e = r0 + t; e < r1; e += T) {
         const uint2 pr = pairs[e];
@@ -173,94 +174,25 @@ k_sort_fine(const uint2 *__restrict__ pairs, const uint32_t *__restrict__ bin_ba
     }
 }
 
-// Exclusive scans over the nbk = W * 2^(c-1) bucket counters, three small launches:
-//   off[b]    = entries before bucket b          segoff[b] = fixed-length segments before bucket b
-// k_msm_scan_local: each workgroup scans SCAN_TILE counters (thread-serial runs + LDS Hillis-Steele) and
-// publishes its totals; k_msm_scan_totals: one workgroup scans the tile totals; k_msm_scan_add adds the
-// tile bases and writes the grand totals off[nbk] / segoff[nbk].
-constexpr uint32_t SCAN_THREADS = 256, SCAN_PER_THREAD = 8, SCAN_TILE = SCAN_THREADS * SCAN_PER_THREAD;
-
-template <class C>
-__global__ void __launch_bounds__(SCAN_THREADS)
-k_msm_scan_local(const uint32_t *__restrict__ hist, uint32_t nbk, uint32_t seg, uint32_t *__restrict__ off, uint32_t *__restrict__ segoff,
-                 uint32_t *__restrict__ tile_a, uint32_t *__restrict__ tile_b) {
-    __shared__ uint32_t sh_a[SCAN_THREADS], sh_b[SCAN_THREADS];
-    const uint32_t t = threadIdx.x, b0 = blockIdx.x * SCAN_TILE + t * SCAN_PER_THREAD;
-    uint32_t h[SCAN_PER_THREAD], sa = 0, sb = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < SCAN_PER_THREAD; k++) {
-        h[k] = (b0 + k < nbk) ? hist[b0 + k] : 0u;
-        sa += h[k]; sb += (h[k] + seg - 1) / seg;
-    }
-    sh_a[t] = sa; sh_b[t] = sb;
-    __syncthreads();
-    for (uint32_t d = 1; d < SCAN_THREADS; d <<= 1) {
-        uint32_t va = 0, vb = 0;
-        if (t >= d) { va = sh_a[t - d]; vb = sh_b[t - d]; }
-        __syncthreads();
-        sh_a[t] += va; sh_b[t] += vb;
-        __syncthreads();
-    }
-    uint32_t ea = sh_a[t] - sa, eb = sh_b[t] - sb;
-#pragma unroll
-    for (uint32_t k = 0; k < SCAN_PER_THREAD; k++) {
-        if (b0 + k < nbk) { off[b0 + k] = ea; segoff[b0 + k] = eb; }
-        ea += h[k]; eb += (h[k] + seg - 1) / seg;
-    }
-    if (t == SCAN_THREADS - 1) { tile_a[blockIdx.x] = sh_a[t]; tile_b[blockIdx.x] = sh_b[t]; }
-}
-
-// in-place exclusive scan of the tile totals by one workgroup; totals land in tile_*[ntiles]
-template <class C>
-__global__ void __launch_bounds__(1024)
-k_msm_scan_totals(uint32_t *__restrict__ tile_a, uint32_t *__restrict__ tile_b, uint32_t ntiles) {
-    __shared__ uint32_t sh_a[1024], sh_b[1024];
-    const uint32_t T = blockDim.x, t = threadIdx.x;
-    const uint32_t per = (ntiles + T - 1) / T, i0 = t * per, i1 = (i0 + per < ntiles) ? i0 + per : ntiles;
-    uint32_t sa = 0, sb = 0;
-    for (uint32_t i = i0; i < i1; i++) { sa += tile_a[i]; sb += tile_b[i]; }
-    sh_a[t] = sa; sh_b[t] = sb;
-    __syncthreads();
-    for (uint32_t d = 1; d < T; d <<= 1) {
-        uint32_t va = 0, vb = 0;
-        if (t >= d) { va = sh_a[t - d]; vb = sh_b[t - d]; }
-        __syncthreads();
-        sh_a[t] += va; sh_b[t] += vb;
-        __syncthreads();
-    }
-    uint32_t ea = sh_a[t] - sa, eb = sh_b[t] - sb;
-    for (uint32_t i = i0; i < i1; i++) { uint32_t a = tile_a[i], b = tile_b[i]; tile_a[i] = ea; tile_b[i] = eb; ea += a; eb += b; }
-    if (t == T - 1) { tile_a[ntiles] = sh_a[t]; tile_b[ntiles] = sh_b[t]; }
-}
-
-template <class C>
-__global__ void
-k_msm_scan_add(uint32_t nbk, uint32_t ntiles, const uint32_t *__restrict__ tile_a,
-                                      const uint32_t *__restrict__ tile_b, uint32_t *__restrict__ off,
-                                      uint32_t *__restrict__ segoff) {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < nbk) { const uint32_t tl = b / SCAN_TILE; off[b] += tile_a[tl]; segoff[b] += tile_b[tl]; }
-    if (b == nbk) { off[nbk] = tile_a[ntiles]; segoff[nbk] = tile_b[ntiles]; }
-}
-
-// thread (Q = 1) or quad of lanes (Q = 4, see Curve::madd_q) per segment; the segment -> bucket map is a binary
-// search in segoff[] (nb + 1 entries)
+// thread (Q = 1) or quad of lanes (Q = 4, see Curve::madd_q) per chunk of rule.len(off[nb]) consecutive sorted entries.
+// Chunk c starts inside bucket b0 (binary search in off[]); its running sum is flushed as "piece" c + b whenever the
+// entries move on to another bucket b, and at its end: piece numbers grow along the entry list, the pieces of bucket b
+// are off[b] / len + b ... (off[b+1] - 1) / len + b.
 template <class C, int Q>
 __global__ void __launch_bounds__(64, C::WAVES_PER_SIMD)
 k_msm_accumulate(const typename C::Affine *__restrict__ table, const uint32_t *__restrict__ sorted,
-                 const uint32_t *__restrict__ off, const uint32_t *__restrict__ segoff, uint32_t nb, uint32_t seg,
+                 const uint32_t *__restrict__ off, uint32_t nb, ChunkRule rule,
                  uint32_t remap_src, uint32_t remap_offset, const uint32_t *__restrict__ remap_pos, uint32_t n_dst,
-                 typename C::XYZZ *__restrict__ segsum) {
-    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x, s = gt / Q, ql = gt % Q;
-    const uint32_t nseg = segoff[nb];
-    if (s >= nseg) return;
-    uint32_t lo = 0, hi = nb;                                  // largest b with segoff[b] <= s
-    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (segoff[mid] <= s) lo = mid; else hi = mid; }
-    const uint32_t b = lo;
-    uint32_t begin = off[b] + (s - segoff[b]) * seg, end = begin + seg;
-    if (end > off[b + 1]) end = off[b + 1];
+                 typename C::XYZZ *__restrict__ piece) {
+    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x, c = gt / Q, ql = gt % Q;
+    const uint32_t total = off[nb], seg = rule.len(total);
+    if ((uint64_t)c * seg >= total) return;
+    const uint32_t begin = c * seg, end = (total - begin < seg) ? total : begin + seg;
+    uint32_t lo = 0, hi = nb;                                  // largest b with off[b] <= begin: the bucket of entry `begin`
+    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (off[mid] <= begin) lo = mid; else hi = mid; }
+    uint32_t b = lo, bucket_end = off[b + 1];
     typename C::XYZZ acc = C::infinity();
-    // software pipeline over the segment: the sorted entry (and, where the registers allow it -- G1 --, the table point)
+    // software pipeline over the chunk: the sorted entry (and, where the registers allow it -- G1 --, the table point)
     // of iteration e + 1 is requested before the mixed addition of iteration e, so the two dependent gather latencies
     // hide behind ~3000 VALU instructions instead of stalling the wave between additions
     constexpr bool PREFETCH_POINT = sizeof(typename C::Affine) <= 64;
@@ -274,12 +206,17 @@ k_msm_accumulate(const typename C::Affine *__restrict__ table, const uint32_t *_
         }
         return idx;
     };
-    uint32_t p_next = begin < end ? sorted[begin] : 0u;
+    uint32_t p_next = sorted[begin];
     typename C::Affine q_next = C::aff_infinity();
     if constexpr (PREFETCH_POINT) {
-        if (begin < end) { const uint32_t idx = entry_index(p_next); if (idx != 0xffffffffu) q_next = table[idx]; }
+        const uint32_t idx = entry_index(p_next); if (idx != 0xffffffffu) q_next = table[idx];
     }
     for (uint32_t e = begin; e < end; e++) {
+        if (e >= bucket_end) {                                  // the entries move on to a later bucket: flush this bucket's piece
+            if (ql == 0) piece[c + b] = acc;
+            acc = C::infinity();
+            do { b++; bucket_end = off[b + 1]; } while (e >= bucket_end);      // (empty buckets in between have no entries, hence no pieces)
+        }
         const uint32_t p = p_next;
         typename C::Affine q;
         if constexpr (PREFETCH_POINT) {
@@ -299,37 +236,40 @@ k_msm_accumulate(const typename C::Affine *__restrict__ table, const uint32_t *_
         if (p >> 31) q = C::neg(q);
         acc = C::template maddQ<Q>(acc, q, ql);                 // an absent entry is the point at infinity: acc unchanged
     }
-    if (ql == 0) segsum[s] = acc;
+    if (ql == 0) piece[c + b] = acc;
 }
 
-// thread / quad per bucket: sum its segment sums (serial; buckets over MSM_HEAVY segments are queued)
+// thread / quad per bucket: sum its chunk pieces (serial; buckets over MSM_HEAVY pieces are queued)
 template <class C, int Q>
 __global__ void __launch_bounds__(64, C::WAVES_PER_SIMD)
-k_msm_bucket_finalize(const typename C::XYZZ *__restrict__ segsum, const uint32_t *__restrict__ segoff,
-                      uint32_t nb, typename C::XYZZ *__restrict__ bucket,
+k_msm_bucket_finalize(const typename C::XYZZ *__restrict__ piece, const uint32_t *__restrict__ off,
+                      uint32_t nb, ChunkRule rule, typename C::XYZZ *__restrict__ bucket,
                       uint32_t *__restrict__ heavy_list, uint32_t *__restrict__ heavy_count) {
     const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x, b = gt / Q, ql = gt % Q;
     if (b >= nb) return;
-    uint32_t s0 = segoff[b], s1 = segoff[b + 1];
-    if (s1 - s0 > MSM_HEAVY) { if (ql == 0) heavy_list[atomicAdd(heavy_count, 1u)] = b; return; }
+    const uint32_t e0 = off[b], e1 = off[b + 1], seg = rule.len(off[nb]);
     typename C::XYZZ acc = C::infinity();
-    for (uint32_t s = s0; s < s1; s++) acc = C::template addQ<Q>(acc, segsum[s], ql);
+    if (e1 > e0) {
+        const uint32_t s0 = e0 / seg + b, s1 = (e1 - 1) / seg + b + 1;
+        if (s1 - s0 > MSM_HEAVY) { if (ql == 0) heavy_list[atomicAdd(heavy_count, 1u)] = b; return; }
+        for (uint32_t s = s0; s < s1; s++) acc = C::template addQ<Q>(acc, piece[s], ql);
+    }
     if (ql == 0) bucket[b] = acc;
 }
 
-// workgroups walk the heavy list; 128 threads / quads stride over the bucket's segments, then an LDS tree.
+// workgroups walk the heavy list; 128 threads / quads stride over the bucket's pieces, then an LDS tree.
 // LDS holds 64 points (the upper half parks, the lower half adds) to stay inside 64 KiB for G2.
 template <class C, int Q>
 __global__ void __launch_bounds__(128 * Q)
-k_msm_heavy(const typename C::XYZZ *__restrict__ segsum, const uint32_t *__restrict__ segoff,
+k_msm_heavy(const typename C::XYZZ *__restrict__ piece, const uint32_t *__restrict__ off, uint32_t nb, ChunkRule rule,
             const uint32_t *__restrict__ heavy_list, const uint32_t *__restrict__ heavy_count,
             typename C::XYZZ *__restrict__ bucket) {
     __shared__ typename C::XYZZ sh[64];
-    const uint32_t nheavy = *heavy_count, lt = threadIdx.x / Q, ql = threadIdx.x % Q;
+    const uint32_t nheavy = *heavy_count, lt = threadIdx.x / Q, ql = threadIdx.x % Q, seg = rule.len(off[nb]);
     for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
-        const uint32_t b = heavy_list[h], s0 = segoff[b], s1 = segoff[b + 1];
+        const uint32_t b = heavy_list[h], s0 = off[b] / seg + b, s1 = (off[b + 1] - 1) / seg + b + 1;
         typename C::XYZZ acc = C::infinity();
-        for (uint32_t s = s0 + lt; s < s1; s += 128) acc = C::template addQ<Q>(acc, segsum[s], ql);
+        for (uint32_t s = s0 + lt; s < s1; s += 128) acc = C::template addQ<Q>(acc, piece[s], ql);
         for (uint32_t half = 64; half > 0; half >>= 1) {
             if (lt >= half && lt < 2 * half && ql == 0) sh[lt - half] = acc;
             __syncthreads();
@@ -377,6 +317,7 @@ k_msm_tree_sum(const typename C::XYZZ *__restrict__ in, uint32_t count, typename
 template <class C>
 int MsmWork<C>::alloc(uint32_t n, uint32_t c, typename C::Affine *shared_table, const MsmShape *sort_like, bool sort_only) {
     if (sort_like) sh = *sort_like; else sh.set(n ? n : 1, c);
+    sh.set_slots(C::WAVES_PER_SIMD);
     if (sh.max_entries() >= (1ull << 31)) return ZK_ERR_ARG;     // entry payload = table index (31 bits) | sign
     const uint32_t G0 = msm_group(sh.nb), K = sh.nb < G0 ? sh.nb : G0, groups = sh.nb / K;
     if (sort_only) { owns_table = false; table_n = n; }
@@ -389,16 +330,12 @@ int MsmWork<C>::alloc(uint32_t n, uint32_t c, typename C::Affine *shared_table, 
         ZK_HIP(hipMalloc(&bin_total, sizeof(uint32_t) * (SORT_MAX_CB + 1)));
         ZK_HIP(hipMalloc(&bin_base, sizeof(uint32_t) * (SORT_MAX_CB + 1)));
         ZK_HIP(hipMalloc(&sorted, sizeof(uint32_t) * sh.max_entries()));
-        ZK_HIP(hipMalloc(&hist, sizeof(uint32_t) * (sh.nb + 1)));
         ZK_HIP(hipMalloc(&off, sizeof(uint32_t) * (sh.nb + 1)));
-        ZK_HIP(hipMalloc(&segoff, sizeof(uint32_t) * (sh.nb + 1)));
-        ZK_HIP(hipMalloc(&tile_a, sizeof(uint32_t) * (zk_div_up(sh.nb, SCAN_TILE) + 1)));
-        ZK_HIP(hipMalloc(&tile_b, sizeof(uint32_t) * (zk_div_up(sh.nb, SCAN_TILE) + 1)));
     }
     if (sort_only) return ZK_OK;
-    ZK_HIP(hipMalloc(&heavy_list, sizeof(uint32_t) * (sh.max_entries() / ((uint64_t)sh.seg * MSM_HEAVY) + 2)));
+    ZK_HIP(hipMalloc(&heavy_list, sizeof(uint32_t) * (sh.max_pieces() / MSM_HEAVY + 2)));
     ZK_HIP(hipMalloc(&heavy_count, sizeof(uint32_t)));
-    ZK_HIP(hipMalloc(&segsum, sizeof(typename C::XYZZ) * sh.max_segments()));
+    ZK_HIP(hipMalloc(&segsum, sizeof(typename C::XYZZ) * sh.max_pieces()));
     ZK_HIP(hipMalloc(&bucket, sizeof(typename C::XYZZ) * sh.nb));
     ZK_HIP(hipMalloc(&partial_a, sizeof(typename C::XYZZ) * (groups + 1)));
     ZK_HIP(hipMalloc(&partial_b, sizeof(typename C::XYZZ) * (zk_div_up(groups, MSM_TREE / sh.quad) + 1)));
@@ -410,7 +347,7 @@ int MsmWork<C>::alloc(uint32_t n, uint32_t c, typename C::Affine *shared_table, 
 template <class C>
 void MsmWork<C>::release() {
     if (!owns_table) table = nullptr;
-    void *dev[] = {table, pairs, counts, bin_total, bin_base, hist, off, segoff, sorted, heavy_list, heavy_count, tile_a, tile_b, segsum, bucket, partial_a, partial_b};
+    void *dev[] = {table, pairs, counts, bin_total, bin_base, off, sorted, heavy_list, heavy_count, segsum, bucket, partial_a, partial_b};
     for (void *p : dev) if (p) hipFree(p);
     if (host_result) hipHostFree(host_result);
     if (ev_acc0) hipEventDestroy(ev_acc0);
@@ -430,20 +367,14 @@ int MsmWork<C>::precompute(const typename C::Affine *d_bases, uint32_t n, hipStr
 template <class C>
 int MsmWork<C>::enqueue_sort(const fe *scalars, const uint32_t *gather, uint32_t n, int canonical, hipStream_t st) {
     if (n != table_n || !sorted) return ZK_ERR_ARG;             // the table stride is the precompute-time n
-    const uint32_t c = sh.c, W = sh.W, nb = sh.nb, seg = sh.seg;
+    const uint32_t c = sh.c, W = sh.W, nb = sh.nb;
     SortShape sq = ss; sq.set(n ? n : 1, nb);                   // same bins; workgroups sized for this call's n
     ZK_LAUNCH_SYNC(k_sort_count<C>, sq.groups, SORT_THREADS, st, scalars, gather, n, canonical, c, W, sq, counts);
     ZK_LAUNCH_SYNC(k_sort_colscan<C>, sq.cb, SORT_THREADS, st, counts, sq.groups, bin_total);
     ZK_LAUNCH_SYNC(k_sort_binscan<C>, 1, SORT_THREADS, st, (const uint32_t *)bin_total, sq.cb, bin_base);
     ZK_LAUNCH_SYNC(k_sort_partition<C>, sq.groups, SORT_THREADS, st, scalars, gather, n, canonical, c, W, sq,
                    (const uint32_t *)counts, (const uint32_t *)bin_base, pairs);
-    ZK_LAUNCH_SYNC(k_sort_fine<C>, sq.cb, SORT_FINE_THREADS, st, (const uint2 *)pairs, (const uint32_t *)bin_base, sq, hist, off, sorted);
-    {   // segments per bucket (and the same off[] again) from the histogram
-        const uint32_t ntiles = zk_div_up(nb, SCAN_TILE);
-        ZK_LAUNCH_SYNC(k_msm_scan_local<C>, ntiles, SCAN_THREADS, st, (const uint32_t *)hist, nb, seg, off, segoff, tile_a, tile_b);
-        ZK_LAUNCH_SYNC(k_msm_scan_totals<C>, 1, 1024, st, tile_a, tile_b, ntiles);
-        ZK_LAUNCH(k_msm_scan_add<C>, zk_div_up(nb + 1, 256), 256, st, nb, ntiles, (const uint32_t *)tile_a, (const uint32_t *)tile_b, off, segoff);
-    }
+    ZK_LAUNCH_SYNC(k_sort_fine<C>, sq.cb, SORT_FINE_THREADS, st, (const uint2 *)pairs, (const uint32_t *)bin_base, sq, off, sorted);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
@@ -461,8 +392,8 @@ template <class C>
 template <int Q>
 int MsmWork<C>::launch_reduce(uint32_t K, uint32_t groups, hipStream_t st) {
     const uint32_t nb = sh.nb;
-    ZK_LAUNCH((k_msm_bucket_finalize<C, Q>), zk_div_up((uint64_t)nb * Q, 64), 64, st, (const typename C::XYZZ *)segsum, (const uint32_t *)cur_segoff, nb, bucket, heavy_list, heavy_count);
-    ZK_LAUNCH_SYNC((k_msm_heavy<C, Q>), MSM_HEAVY_GRID, 128 * Q, st, (const typename C::XYZZ *)segsum, (const uint32_t *)cur_segoff,
+    ZK_LAUNCH((k_msm_bucket_finalize<C, Q>), zk_div_up((uint64_t)nb * Q, 64), 64, st, (const typename C::XYZZ *)segsum, (const uint32_t *)cur_off, nb, sh.chunk, bucket, heavy_list, heavy_count);
+    ZK_LAUNCH_SYNC((k_msm_heavy<C, Q>), MSM_HEAVY_GRID, 128 * Q, st, (const typename C::XYZZ *)segsum, (const uint32_t *)cur_off, nb, sh.chunk,
                    (const uint32_t *)heavy_list, (const uint32_t *)heavy_count, bucket);
     ZK_LAUNCH((k_msm_group_reduce<C, Q>), zk_div_up((uint64_t)groups * Q, 64), 64, st, (const typename C::XYZZ *)bucket, nb, K, partial_a);
     typename C::XYZZ *cur = partial_a, *nxt = partial_b;
@@ -478,23 +409,23 @@ int MsmWork<C>::launch_reduce(uint32_t K, uint32_t groups, hipStream_t st) {
 
 template <class C>
 int MsmWork<C>::enqueue_reduce(const SortView &v, hipStream_t st, hipStream_t st_tail) {
-    if (!v.sorted || v.seg != sh.seg) return ZK_ERR_ARG;        // a borrowed sort must have this MSM's shape
-    const uint32_t nb = sh.nb, seg = sh.seg;
+    if (!v.sorted || v.nb != sh.nb) return ZK_ERR_ARG;          // a borrowed sort must have this MSM's buckets
+    const uint32_t nb = sh.nb;
     const uint32_t G0 = msm_group(nb), K = nb < G0 ? nb : G0, groups = nb / K;
     ZK_HIP(hipMemsetAsync(heavy_count, 0, sizeof(uint32_t), st));
-    // segment count is only known on the device: launch for the upper bound, threads past segoff[nb] exit.
-    const uint64_t max_seg = (uint64_t)v.entries_bound / seg + nb + 1;
-    if (max_seg > sh.max_segments()) return ZK_ERR_ARG;
+    // the entry count is only known on the device: launch for the most chunks it can give, threads past the end exit
+    const uint64_t max_seg = sh.chunk.max_chunks(v.entries_bound);
+    if (max_seg + nb + 1 > sh.max_pieces()) return ZK_ERR_ARG;
     ZK_HIP(hipEventRecord(ev_acc0, st));
     if (sh.quad_acc == 4)
-        ZK_LAUNCH((k_msm_accumulate<C, 4>), zk_div_up(max_seg * 4, 64), 64, st, (const typename C::Affine *)table, v.sorted, v.off, v.segoff,
-                  nb, seg, v.remap_src, v.remap_offset, v.remap_pos, table_n, segsum);
+        ZK_LAUNCH((k_msm_accumulate<C, 4>), zk_div_up(max_seg * 4, 64), 64, st, (const typename C::Affine *)table, v.sorted, v.off,
+                  nb, sh.chunk, v.remap_src, v.remap_offset, v.remap_pos, table_n, segsum);
     else
-        ZK_LAUNCH((k_msm_accumulate<C, 1>), zk_div_up(max_seg, 64), 64, st, (const typename C::Affine *)table, v.sorted, v.off, v.segoff,
-                  nb, seg, v.remap_src, v.remap_offset, v.remap_pos, table_n, segsum);
+        ZK_LAUNCH((k_msm_accumulate<C, 1>), zk_div_up(max_seg, 64), 64, st, (const typename C::Affine *)table, v.sorted, v.off,
+                  nb, sh.chunk, v.remap_src, v.remap_offset, v.remap_pos, table_n, segsum);
     ZK_HIP(hipEventRecord(ev_acc1, st));
     if (st_tail != st) { ZK_HIP(hipStreamWaitEvent(st_tail, ev_acc1, 0)); st = st_tail; }
-    cur_segoff = v.segoff;
+    cur_off = v.off;
     const int rc = sh.quad == 4 ? launch_reduce<4>(K, groups, st) : launch_reduce<1>(K, groups, st);
     if (rc != ZK_OK) return rc;
     typename C::XYZZ *cur = (tree_levels(groups) & 1) ? partial_b : partial_a;
