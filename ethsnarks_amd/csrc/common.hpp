@@ -30,6 +30,7 @@ inline int hip_fail(hipError_t e, const char *what, const char *file, int line) 
     snprintf(g_last_error, sizeof(g_last_error), "%s failed: %s (%s:%d)", what, hipGetErrorString(e), file, line);
     return ZK_ERR_HIP;
 }
+inline int fail_msg(int code, const char *msg) { snprintf(g_last_error, sizeof(g_last_error), "%s", msg); return code; }
 }  // namespace zk
 #define ZK_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return zk::hip_fail(e_, #call, __FILE__, __LINE__); } while (0)
 #define ZK_TRY(call) do { int rc_ = (call); if (rc_ != ZK_OK) return rc_; } while (0)

@@ -5,7 +5,15 @@
 // scalar (MSB-first double-and-add in XYZZ, then one inversion to affine).  A table-driven windowed
 // variant would be faster; key generation is off the proving path, so the simple form is kept.
 #pragma once
+#include <vector>
 #include "bn254.hpp"
+
+// verification key object of the C ABI (zk_keygen output, zk_vk_from_json / zk_vk_to_json): the members of
+// r1cs_gg_ppzksnark_zok_verification_key (r1cs_gg_ppzksnark_zok.hpp), affine Montgomery
+struct zk_vk {
+    zk::G1::Affine alpha_g1; zk::G2::Affine beta_g2, gamma_g2, delta_g2;
+    std::vector<zk::G1::Affine> gamma_abc;
+};
 
 namespace zk {
 

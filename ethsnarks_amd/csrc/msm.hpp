@@ -41,35 +41,30 @@ constexpr uint32_t MSM_SEG_MAX = 64;      // ... upper bound: above it the entri
 constexpr uint32_t MSM_HEAVY = 64;        // buckets with more chunk pieces than this are reduced by a workgroup
 constexpr uint32_t MSM_GROUP = 8;         // buckets per running-sum thread (ZK_MSM_GROUP overrides: tuning aid)
 constexpr uint32_t MSM_GROUP_SMALL = 4;   // ... for <= 2^15 buckets (latency-bound sizes; measured at 2^12 / 2^15 / 2^18, tools/dev_small_sweep.sh)
-inline uint32_t msm_group(uint32_t nb) {
+inline uint32_t msm_group(uint32_t nb) {      // read once per MsmShape::set (context creation), never on the proving path
     if (const char *e = getenv("ZK_MSM_GROUP")) { int v = atoi(e); if (v >= 1 && v <= 1024) return (uint32_t)v; }
     return nb <= (1u << 15) ? MSM_GROUP_SMALL : MSM_GROUP;
 }
 constexpr uint32_t MSM_TREE = 256;        // fan-in (= workgroup size) of the final tree sum
-#ifdef ZK_EMUL
-constexpr uint32_t MSM_HEAVY_GRID = 2;    // the emulator spawns a real thread per GPU thread
-#else
-constexpr uint32_t MSM_HEAVY_GRID = 256;
-#endif
+constexpr uint32_t MSM_HEAVY_GRID = 256;  // workgroups that walk the heavy-bucket list
 
-// shapes of the two-pass bucket sort (msm_impl.hpp)
+// shapes of the two-pass bucket sort (msm_impl.hpp); the CPU emulation of tests/emul runs these same shapes
 constexpr uint32_t SORT_THREADS = 256;
-#ifdef ZK_EMUL
-constexpr uint32_t SORT_FINE_THREADS = 64;      // the emulator runs one fiber per GPU thread
-#else
 constexpr uint32_t SORT_FINE_THREADS = 1024;
-#endif
 constexpr uint32_t SORT_MAX_CB = 256;          // coarse bins
 constexpr uint32_t SORT_MAX_FB = 4096;         // fine buckets per coarse bin held in LDS (c <= 20)
 
 struct SortShape {
     uint32_t cb, fb, fine_bits, groups, per_group;   // groups = workgroups of pass 1, per_group = scalars each
-    void set(uint32_t n, uint32_t nb) {
+    void set(uint32_t n, uint32_t nb) {               // context creation: reads the tuning override once
+        per_group = 1024;                                   // 1024 scalars x W windows of LDS-ranked entries per workgroup
+        if (const char *e = getenv("ZK_SORT_PER_GROUP")) { int v = atoi(e); if (v >= 64) per_group = (uint32_t)v; }   // tuning aid
+        resize(n, nb);
+    }
+    void resize(uint32_t n, uint32_t nb) {            // same bins and per_group for another scalar count (proving path: no getenv)
         cb = nb < SORT_MAX_CB ? nb : SORT_MAX_CB;
         fb = nb / cb;
         fine_bits = 0; while ((1u << fine_bits) < fb) fine_bits++;
-        per_group = 1024;                                   // 1024 scalars x W windows of LDS-ranked entries per workgroup
-        if (const char *e = getenv("ZK_SORT_PER_GROUP")) { int v = atoi(e); if (v >= 64) per_group = (uint32_t)v; }   // tuning aid
         groups = (n + per_group - 1) / per_group; if (!groups) groups = 1;
     }
 };
@@ -104,6 +99,7 @@ inline uint32_t msm_machine_threads(uint32_t waves_per_simd) {
 
 struct MsmShape {
     uint32_t n = 0, c = 0, W = 0, nb = 0;
+    uint32_t group = MSM_GROUP;     // buckets per running-sum thread
     ChunkRule chunk;
     uint32_t quad = 1;      // lanes per logical thread in the bucket-reduction kernels: 1, or 4 (Curve::*_q) for latency-bound sizes
     uint32_t quad_acc = 1;  // ... and in the accumulation kernel (only while 4 lanes per segment still fit the machine at once)
@@ -118,6 +114,7 @@ struct MsmShape {
         if (c < 2) c = 2;
         if (c > 20) c = 20;
         W = 254 / c + 1; nb = 1u << (c - 1);
+        group = msm_group(nb);
         // measured (tools/dev_small_sweep.sh, domains 2^13 .. 2^19): quad reductions win up to 2^17 constraints with one or
         // three proofs in flight (and still for a single proof beyond); quad accumulation only while the GPU is mostly idle
         quad = max_entries() <= (1ull << 21) ? 4 : 1;

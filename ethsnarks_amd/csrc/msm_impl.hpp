@@ -318,8 +318,8 @@ template <class C>
 int MsmWork<C>::alloc(uint32_t n, uint32_t c, typename C::Affine *shared_table, const MsmShape *sort_like, bool sort_only) {
     if (sort_like) sh = *sort_like; else sh.set(n ? n : 1, c);
     sh.set_slots(C::WAVES_PER_SIMD);
-    if (sh.max_entries() >= (1ull << 31)) return ZK_ERR_ARG;     // entry payload = table index (31 bits) | sign
-    const uint32_t G0 = msm_group(sh.nb), K = sh.nb < G0 ? sh.nb : G0, groups = sh.nb / K;
+    if (sh.max_entries() >= (1ull << 31)) return fail_msg(ZK_ERR_ARG, "MSM too large: n * windows must stay below 2^31 (entry payload = table index | sign)");
+    const uint32_t G0 = sh.group, K = sh.nb < G0 ? sh.nb : G0, groups = sh.nb / K;
     if (sort_only) { owns_table = false; table_n = n; }
     else if (shared_table) { table = shared_table; owns_table = false; table_n = n; }
     else ZK_HIP(hipMalloc(&table, sizeof(typename C::Affine) * (size_t)(n ? n : 1) * sh.W));
@@ -357,7 +357,7 @@ void MsmWork<C>::release() {
 
 template <class C>
 int MsmWork<C>::precompute(const typename C::Affine *d_bases, uint32_t n, hipStream_t st) {
-    if (n > sh.n) return ZK_ERR_ARG;
+    if (n > sh.n) return fail_msg(ZK_ERR_ARG, "MSM precompute: more bases than the shape was allocated for");
     table_n = n;
     if (n) ZK_LAUNCH(k_msm_precompute<C>, zk_div_up(n, 64), 64, st, d_bases, n, sh.c, sh.W, table);
     ZK_HIP(hipGetLastError());
@@ -366,9 +366,9 @@ int MsmWork<C>::precompute(const typename C::Affine *d_bases, uint32_t n, hipStr
 
 template <class C>
 int MsmWork<C>::enqueue_sort(const fe *scalars, const uint32_t *gather, uint32_t n, int canonical, hipStream_t st) {
-    if (n != table_n || !sorted) return ZK_ERR_ARG;             // the table stride is the precompute-time n
+    if (n != table_n || !sorted) return fail_msg(ZK_ERR_ARG, "MSM sort: scalar count differs from the table's base count");   // the table stride is the precompute-time n
     const uint32_t c = sh.c, W = sh.W, nb = sh.nb;
-    SortShape sq = ss; sq.set(n ? n : 1, nb);                   // same bins; workgroups sized for this call's n
+    SortShape sq = ss; sq.resize(n ? n : 1, nb);                // same bins; workgroups sized for this call's n
     ZK_LAUNCH_SYNC(k_sort_count<C>, sq.groups, SORT_THREADS, st, scalars, gather, n, canonical, c, W, sq, counts);
     ZK_LAUNCH_SYNC(k_sort_colscan<C>, sq.cb, SORT_THREADS, st, counts, sq.groups, bin_total);
     ZK_LAUNCH_SYNC(k_sort_binscan<C>, 1, SORT_THREADS, st, (const uint32_t *)bin_total, sq.cb, bin_base);
@@ -409,13 +409,13 @@ int MsmWork<C>::launch_reduce(uint32_t K, uint32_t groups, hipStream_t st) {
 
 template <class C>
 int MsmWork<C>::enqueue_reduce(const SortView &v, hipStream_t st, hipStream_t st_tail) {
-    if (!v.sorted || v.nb != sh.nb) return ZK_ERR_ARG;          // a borrowed sort must have this MSM's buckets
+    if (!v.sorted || v.nb != sh.nb) return fail_msg(ZK_ERR_ARG, "MSM reduce: the driving sort has a different bucket count");   // a borrowed sort must have this MSM's buckets
     const uint32_t nb = sh.nb;
-    const uint32_t G0 = msm_group(nb), K = nb < G0 ? nb : G0, groups = nb / K;
+    const uint32_t G0 = sh.group, K = nb < G0 ? nb : G0, groups = nb / K;
     ZK_HIP(hipMemsetAsync(heavy_count, 0, sizeof(uint32_t), st));
     // the entry count is only known on the device: launch for the most chunks it can give, threads past the end exit
     const uint64_t max_seg = sh.chunk.max_chunks(v.entries_bound);
-    if (max_seg + nb + 1 > sh.max_pieces()) return ZK_ERR_ARG;
+    if (max_seg + nb + 1 > sh.max_pieces()) return fail_msg(ZK_ERR_ARG, "MSM reduce: the driving sort has more entries than this MSM was allocated for");
     ZK_HIP(hipEventRecord(ev_acc0, st));
     if (sh.quad_acc == 4)
         ZK_LAUNCH((k_msm_accumulate<C, 4>), zk_div_up(max_seg * 4, 64), 64, st, (const typename C::Affine *)table, v.sorted, v.off,

@@ -13,6 +13,7 @@
 #include <vector>
 #include <string.h>
 #include "bn254.hpp"
+#include "keygen.hpp"
 #include "../../include/zkhip.h"
 
 using namespace zk;
@@ -205,29 +206,66 @@ template <class C> typename C::XYZZ scalar_mul(const typename C::Affine &p, cons
     }
     return acc;
 }
-}  // namespace
 
-extern "C" int zk_verify(const char *vk_json, const char *proof_json, int *accepted) {
-    if (!vk_json || !proof_json || !accepted) return vfail(ZK_ERR_ARG, "null argument");
-    *accepted = 0;
-    const std::string vk(vk_json), pf(proof_json);
+// vk_from_json (src/import.cpp:195-223): keys alpha, beta, gamma, delta, gammaABC
+bool parse_vk(const std::string &vk, zk_vk &out) {
     std::vector<std::string> s;
-    G1::Affine alpha, A, Cc; G2::Affine beta, gamma, delta, B;
-    std::vector<G1::Affine> ic;
-    std::vector<fe> inputs;
     bool ok = true;
-    s.clear(); ok = ok && json_strings(vk, "alpha", s) && s.size() == 2 && g1_from(s, 0, alpha);
-    s.clear(); ok = ok && json_strings(vk, "beta", s) && s.size() == 4 && g2_from(s, 0, beta);
-    s.clear(); ok = ok && json_strings(vk, "gamma", s) && s.size() == 4 && g2_from(s, 0, gamma);
-    s.clear(); ok = ok && json_strings(vk, "delta", s) && s.size() == 4 && g2_from(s, 0, delta);
+    s.clear(); ok = ok && json_strings(vk, "alpha", s) && s.size() == 2 && g1_from(s, 0, out.alpha_g1);
+    s.clear(); ok = ok && json_strings(vk, "beta", s) && s.size() == 4 && g2_from(s, 0, out.beta_g2);
+    s.clear(); ok = ok && json_strings(vk, "gamma", s) && s.size() == 4 && g2_from(s, 0, out.gamma_g2);
+    s.clear(); ok = ok && json_strings(vk, "delta", s) && s.size() == 4 && g2_from(s, 0, out.delta_g2);
     s.clear(); ok = ok && json_strings(vk, "gammaABC", s) && s.size() >= 2 && s.size() % 2 == 0;
-    if (ok) { ic.resize(s.size() / 2); for (size_t i = 0; i < ic.size() && ok; i++) ok = g1_from(s, 2 * i, ic[i]); }
+    if (ok) { out.gamma_abc.resize(s.size() / 2); for (size_t i = 0; i < out.gamma_abc.size() && ok; i++) ok = g1_from(s, 2 * i, out.gamma_abc[i]); }
+    return ok;
+}
+// proof_from_json (src/import.cpp:161-192): keys A, B, C, input; inputs come back canonical
+bool parse_proof(const std::string &pf, G1::Affine &A, G2::Affine &B, G1::Affine &Cc, std::vector<fe> &inputs) {
+    std::vector<std::string> s;
+    bool ok = true;
     s.clear(); ok = ok && json_strings(pf, "A", s) && s.size() == 2 && g1_from(s, 0, A);
     s.clear(); ok = ok && json_strings(pf, "B", s) && s.size() == 4 && g2_from(s, 0, B);
     s.clear(); ok = ok && json_strings(pf, "C", s) && s.size() == 2 && g1_from(s, 0, Cc);
     s.clear(); ok = ok && json_strings(pf, "input", s);
     if (ok) { inputs.resize(s.size()); for (size_t i = 0; i < s.size() && ok; i++) ok = parse_big(s[i], inputs[i]) && lt_modulus_r(inputs[i]); }
-    if (!ok) return vfail(ZK_ERR_FORMAT, "cannot parse verification key / proof JSON");   // reference: std::invalid_argument / json exception
+    return ok;
+}
+}  // namespace
+
+extern "C" int zk_vk_from_json(const char *vk_json, zk_vk **out) {
+    if (!vk_json || !out) return vfail(ZK_ERR_ARG, "null argument");
+    zk_vk *vk = new (std::nothrow) zk_vk();
+    if (!vk) return ZK_ERR_NOMEM;
+    if (!parse_vk(vk_json, *vk)) { delete vk; return vfail(ZK_ERR_FORMAT, "cannot parse verification key JSON"); }
+    *out = vk;
+    return ZK_OK;
+}
+
+extern "C" int zk_proof_from_json(const char *proof_json, zk_proof *out, uint64_t *inputs_canon, uint32_t cap, uint32_t *n_inputs) {
+    if (!proof_json || !out || !n_inputs) return vfail(ZK_ERR_ARG, "null argument");
+    G1::Affine A, Cc; G2::Affine B; std::vector<fe> in;
+    if (!parse_proof(proof_json, A, B, Cc, in)) return vfail(ZK_ERR_FORMAT, "cannot parse proof JSON");
+    memset(out, 0, sizeof(*out));
+    auto put = [](uint64_t dst[4], const fe &mont) { fe c = Fq::from_mont(mont); memcpy(dst, c.l, 32); };
+    put(out->a_x, A.x); put(out->a_y, A.y);
+    put(out->b_x_c0, B.x.c0); put(out->b_x_c1, B.x.c1); put(out->b_y_c0, B.y.c0); put(out->b_y_c1, B.y.c1);
+    put(out->c_x, Cc.x); put(out->c_y, Cc.y);
+    *n_inputs = (uint32_t)in.size();
+    if (in.size() > cap || (in.size() && !inputs_canon)) return vfail(ZK_ERR_BUFFER, "input buffer too small");
+    for (size_t i = 0; i < in.size(); i++) memcpy(inputs_canon + 4 * i, in[i].l, 32);
+    return ZK_OK;
+}
+
+extern "C" int zk_verify(const char *vk_json, const char *proof_json, int *accepted) {
+    if (!vk_json || !proof_json || !accepted) return vfail(ZK_ERR_ARG, "null argument");
+    *accepted = 0;
+    zk_vk key;
+    G1::Affine A, Cc; G2::Affine B;
+    std::vector<fe> inputs;
+    if (!parse_vk(vk_json, key) || !parse_proof(proof_json, A, B, Cc, inputs))
+        return vfail(ZK_ERR_FORMAT, "cannot parse verification key / proof JSON");   // reference: std::invalid_argument / json exception
+    const G1::Affine &alpha = key.alpha_g1; const G2::Affine &beta = key.beta_g2, &gamma = key.gamma_g2, &delta = key.delta_g2;
+    const std::vector<G1::Affine> &ic = key.gamma_abc;
     if (inputs.size() + 1 != ic.size()) return ZK_OK;                         // strong input consistency, tcc:646-654
     // well-formedness, tcc:585-592 (points on their curves; B in the order-r subgroup of the twist)
     if (!g1_on_curve(A) || !g1_on_curve(Cc) || !g2_on_curve(B)) return ZK_OK;

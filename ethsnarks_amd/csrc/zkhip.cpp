@@ -22,7 +22,7 @@
 namespace zk { thread_local char g_last_error[256] = ""; }
 using namespace zk;
 
-static int fail(int code, const char *msg) { snprintf(g_last_error, sizeof(g_last_error), "%s", msg); return code; }
+static int fail(int code, const char *msg) { return fail_msg(code, msg); }
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 static_assert(sizeof(G1::Affine) == 64 && sizeof(G2::Affine) == 128, "affine layouts must match the .raw / libff memory image");
@@ -120,13 +120,19 @@ extern "C" const void *zk_pk_part(const zk_pk *pk, int which) {
 }
 extern "C" void zk_pk_free(zk_pk *pk) { delete pk; }
 
-// ---- .raw stream, upstream libff layout under BINARY_OUTPUT + MONTGOMERY_OUTPUT + NO_PT_COMPRESSION
-// (CMakeLists.txt:115-131,186-188): point = ASCII '0'/'1' infinity flag + raw Montgomery limbs
-// (G1: X Y; G2: X.c0 X.c1 Y.c0 Y.c1); infinity carries affine X = 0, Y = 1; vector = decimal size
-// "\n" elements; sparse_vector = domain "\n" count "\n" indices (one per line) count "\n" elements.
+// ---- .raw stream under BINARY_OUTPUT + MONTGOMERY_OUTPUT + NO_PT_COMPRESSION (CMakeLists.txt:115-131,186-188):
+// point = ASCII '0'/'1' infinity flag + raw Montgomery limbs (G1: X Y; G2: X.c0 X.c1 Y.c0 Y.c1); infinity carries affine
+// X = 0, Y = 1; vector = decimal size "\n" elements; sparse_vector = domain "\n" count "\n" indices (one per line)
+// count "\n" elements; knowledge_commitment<G2, G1> = g then h.
+//   ZK_CODEC_ALT_BN128: upstream libff alt_bn128_G1/G2 stream operators.
+//   ZK_CODEC_MCL_BN128: the fork's default curve build (CMakeLists.txt:47-54).  Its mcl_bn128_G1/G2 stream operators are
+//     in the ABSENT libff fork; inferred from upstream libff's bn128 (ate-pairing) wrapper they are modelled on: the same
+//     flag + raw coordinate memory, and mcl keeps Fp in Montgomery form with R = 2^256 -- i.e. the SAME BYTES.
+//     PARITY UNPINNED: the reference holds no key file; a verified layout would replace point()/put_point() below.
 namespace {
+bool codec_known(int codec) { return codec == ZK_CODEC_ALT_BN128 || codec == ZK_CODEC_MCL_BN128; }
 struct RawReader {
-    FILE *f; bool bad = false;
+    FILE *f; int codec; bool bad = false;
     template <class P> void point(P &p) {
         int c = fgetc(f);
         if (c != '0' && c != '1') { bad = true; return; }
@@ -145,38 +151,48 @@ struct RawReader {
         v.resize(n);
         for (uint64_t i = 0; i < n && !bad; i++) point(v[i]);
     }
+    // sparse_vector header: domain, indices; returns the value count
+    uint64_t sparse_head(uint32_t &domain, std::vector<uint32_t> &idx) {
+        if (bad) return 0;
+        domain = (uint32_t)size();
+        uint64_t n = size();
+        if (bad || n > (1ull << 28) + 1) { bad = true; return 0; }
+        idx.resize(n);
+        for (uint64_t i = 0; i < n && !bad; i++) {
+            idx[i] = (uint32_t)size();
+            if (idx[i] >= domain || (i && idx[i] <= idx[i - 1])) bad = true;
+        }
+        uint64_t nv = size();
+        if (nv != n) bad = true;
+        return bad ? 0 : nv;
+    }
 };
-template <class P> void raw_put_point(FILE *f, const P &p, bool inf, const P &inf_image) {
-    fputc(inf ? '1' : '0', f);
-    fwrite(inf ? &inf_image : &p, sizeof(P), 1, f);
-}
+struct RawWriter {
+    FILE *f; int codec;
+    G1::Affine i1; G2::Affine i2;
+    RawWriter(FILE *f_, int codec_) : f(f_), codec(codec_) { i1.x = Fq::zero(); i1.y = Fq::one(); i2.x = Fq2::zero(); i2.y = Fq2::one(); }
+    void point(const G1::Affine &p) { const bool inf = G1::is_inf(p); fputc(inf ? '1' : '0', f); fwrite(inf ? &i1 : &p, sizeof(p), 1, f); }
+    void point(const G2::Affine &p) { const bool inf = G2::is_inf(p); fputc(inf ? '1' : '0', f); fwrite(inf ? &i2 : &p, sizeof(p), 1, f); }
+    template <class P> void points(const std::vector<P> &v) { fprintf(f, "%zu\n", v.size()); for (auto &p : v) point(p); }
+    void sparse_head(uint32_t domain, const std::vector<uint32_t> &idx) {
+        fprintf(f, "%u\n%zu\n", domain, idx.size());
+        for (uint32_t i : idx) fprintf(f, "%u\n", i);
+        fprintf(f, "%zu\n", idx.size());
+    }
+};
 }  // namespace
 
 extern "C" int zk_pk_load_raw(const char *path, int codec, zk_pk **out) {
     if (!path || !out) return fail(ZK_ERR_ARG, "null argument");
-    if (codec != ZK_CODEC_ALT_BN128) return fail(ZK_ERR_ARG, "unsupported codec (only ZK_CODEC_ALT_BN128)");
+    if (!codec_known(codec)) return fail(ZK_ERR_ARG, "unsupported codec (ZK_CODEC_ALT_BN128 or ZK_CODEC_MCL_BN128)");
     FILE *f = fopen(path, "rb");
     if (!f) return fail(ZK_ERR_IO, "cannot open proving key file");       // reference: assert(fh.is_open()), utils.hpp:180
     zk_pk *pk = new (std::nothrow) zk_pk();
     if (!pk) { fclose(f); return ZK_ERR_NOMEM; }
-    RawReader r{f};
+    RawReader r{f, codec};
     r.point(pk->alpha_g1); r.point(pk->beta_g1); r.point(pk->beta_g2); r.point(pk->delta_g1); r.point(pk->delta_g2);
-    auto sparse = [&](uint32_t &domain, std::vector<uint32_t> &idx, auto &vals) {
-        if (r.bad) return;
-        domain = (uint32_t)r.size();
-        uint64_t n = r.size();
-        if (r.bad || n > (1ull << 28) + 1) { r.bad = true; return; }
-        idx.resize(n);
-        for (uint64_t i = 0; i < n && !r.bad; i++) {
-            idx[i] = (uint32_t)r.size();
-            if (idx[i] >= domain || (i && idx[i] <= idx[i - 1])) r.bad = true;
-        }
-        uint64_t nv = r.size();
-        if (nv != n) r.bad = true;
-        r.points(vals, nv);
-    };
-    sparse(pk->a_domain, pk->a_idx, pk->a_val);
-    sparse(pk->b_domain, pk->b_idx, pk->b_val);
+    r.points(pk->a_val, r.sparse_head(pk->a_domain, pk->a_idx));
+    r.points(pk->b_val, r.sparse_head(pk->b_domain, pk->b_idx));
     if (!r.bad) r.points(pk->H, r.size());
     if (!r.bad) r.points(pk->L, r.size());
     fclose(f);
@@ -187,29 +203,108 @@ extern "C" int zk_pk_load_raw(const char *path, int codec, zk_pk **out) {
 
 extern "C" int zk_pk_save_raw(const zk_pk *pk, const char *path, int codec) {
     if (!pk || !path) return fail(ZK_ERR_ARG, "null argument");
-    if (codec != ZK_CODEC_ALT_BN128) return fail(ZK_ERR_ARG, "unsupported codec");
+    if (!codec_known(codec)) return fail(ZK_ERR_ARG, "unsupported codec (ZK_CODEC_ALT_BN128 or ZK_CODEC_MCL_BN128)");
     FILE *f = fopen(path, "wb");
     if (!f) return fail(ZK_ERR_IO, "cannot create proving key file");
-    G1::Affine i1; i1.x = Fq::zero(); i1.y = Fq::one();
-    G2::Affine i2; i2.x = Fq2::zero(); i2.y = Fq2::one();
-    auto p1 = [&](const G1::Affine &p) { raw_put_point(f, p, G1::is_inf(p), i1); };
-    auto p2 = [&](const G2::Affine &p) { raw_put_point(f, p, G2::is_inf(p), i2); };
-    p1(pk->alpha_g1); p1(pk->beta_g1); p2(pk->beta_g2); p1(pk->delta_g1); p2(pk->delta_g2);
-    fprintf(f, "%u\n%zu\n", pk->a_domain, pk->a_idx.size());
-    for (uint32_t i : pk->a_idx) fprintf(f, "%u\n", i);
-    fprintf(f, "%zu\n", pk->a_val.size());
-    for (auto &p : pk->a_val) p1(p);
-    fprintf(f, "%u\n%zu\n", pk->b_domain, pk->b_idx.size());
-    for (uint32_t i : pk->b_idx) fprintf(f, "%u\n", i);
-    fprintf(f, "%zu\n", pk->b_val.size());
-    for (auto &p : pk->b_val) p2(p);
-    fprintf(f, "%zu\n", pk->H.size());
-    for (auto &p : pk->H) p1(p);
-    fprintf(f, "%zu\n", pk->L.size());
-    for (auto &p : pk->L) p1(p);
+    RawWriter w(f, codec);
+    w.point(pk->alpha_g1); w.point(pk->beta_g1); w.point(pk->beta_g2); w.point(pk->delta_g1); w.point(pk->delta_g2);
+    w.sparse_head(pk->a_domain, pk->a_idx); for (auto &p : pk->a_val) w.point(p);
+    w.sparse_head(pk->b_domain, pk->b_idx); for (auto &p : pk->b_val) w.point(p);
+    w.points(pk->H); w.points(pk->L);
     bool bad = ferror(f) != 0;
     if (fclose(f) != 0) bad = true;
     return bad ? fail(ZK_ERR_IO, "write error") : ZK_OK;
+}
+
+// ---- the reference's offline key converters over the FULL (zero-knowledge) proving key stream, tcc:53-90:
+// alpha_g1 beta_g1 beta_g2 delta_g1 delta_g2, A_query (vector<G1>, V + 1 entries, zeros included), B_query
+// (knowledge_commitment_vector<G2, G1>: sparse, each value = G2 then G1), H_query, L_query.
+namespace {
+struct FullKey {
+    G1::Affine alpha_g1, beta_g1, delta_g1; G2::Affine beta_g2, delta_g2;
+    std::vector<G1::Affine> A, Bh, H, L;
+    uint32_t b_domain = 0; std::vector<uint32_t> b_idx; std::vector<G2::Affine> Bg;
+};
+int full_load(const char *path, int codec, FullKey &k) {
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(ZK_ERR_IO, "cannot open proving key file");
+    RawReader r{f, codec};
+    r.point(k.alpha_g1); r.point(k.beta_g1); r.point(k.beta_g2); r.point(k.delta_g1); r.point(k.delta_g2);
+    if (!r.bad) r.points(k.A, r.size());
+    const uint64_t nb = r.sparse_head(k.b_domain, k.b_idx);
+    k.Bg.resize(nb); k.Bh.resize(nb);
+    for (uint64_t i = 0; i < nb && !r.bad; i++) { r.point(k.Bg[i]); r.point(k.Bh[i]); }
+    if (!r.bad) r.points(k.H, r.size());
+    if (!r.bad) r.points(k.L, r.size());
+    fclose(f);
+    return r.bad ? fail(ZK_ERR_FORMAT, "malformed proving key stream") : ZK_OK;
+}
+int full_save(const char *path, int codec, const FullKey &k) {
+    FILE *f = fopen(path, "wb");
+    if (!f) return fail(ZK_ERR_IO, "cannot create proving key file");
+    RawWriter w(f, codec);
+    w.point(k.alpha_g1); w.point(k.beta_g1); w.point(k.beta_g2); w.point(k.delta_g1); w.point(k.delta_g2);
+    w.points(k.A);
+    w.sparse_head(k.b_domain, k.b_idx);
+    for (size_t i = 0; i < k.Bg.size(); i++) { w.point(k.Bg[i]); w.point(k.Bh[i]); }
+    w.points(k.H); w.points(k.L);
+    bool bad = ferror(f) != 0;
+    if (fclose(f) != 0) bad = true;
+    return bad ? fail(ZK_ERR_IO, "write error") : ZK_OK;
+}
+// G1T_alt2mcl / G2T_alt2mcl (export.cpp:330-350): every coordinate travels as the DECIMAL string of its canonical value
+// (bigintToString(X.as_bigint())) and is parsed again on the other side; Z is 1, or the point is (0, 1, 0)
+std::string fq_to_decimal(const fe &mont) {
+    fe c = Fq::from_mont(mont);
+    uint32_t l[8]; for (int i = 0; i < 8; i++) l[i] = c.l[i];
+    std::string out;
+    for (;;) {
+        uint64_t rem = 0; bool any = false;
+        for (int i = 7; i >= 0; i--) { uint64_t cur = (rem << 32) | l[i]; l[i] = (uint32_t)(cur / 1000000000u); rem = cur % 1000000000u; any |= l[i] != 0; }
+        char buf[16]; snprintf(buf, sizeof(buf), any ? "%09u" : "%u", (unsigned)rem);
+        out.insert(0, buf);
+        if (!any) break;
+    }
+    return out;
+}
+bool fq_from_decimal_str(const std::string &s, fe &out) {
+    fe acc = Fq::zero(); const fe ten = Fq::from_u64(10);
+    if (s.empty()) return false;
+    for (char ch : s) { if (ch < '0' || ch > '9') return false; acc = Fq::add(Fq::mul(acc, ten), Fq::from_u64((uint64_t)(ch - '0'))); }
+    out = acc; return true;
+}
+bool through_decimal(fe &v) { return fq_from_decimal_str(fq_to_decimal(v), v); }
+bool through_decimal(G1::Affine &p) { return G1::is_inf(p) || (through_decimal(p.x) && through_decimal(p.y)); }
+bool through_decimal(G2::Affine &p) { return G2::is_inf(p) || (through_decimal(p.x.c0) && through_decimal(p.x.c1) && through_decimal(p.y.c0) && through_decimal(p.y.c1)); }
+}  // namespace
+
+// pk_alt2mcl (src/export.cpp:352-397)
+extern "C" int zk_pk_alt2mcl(const char *alt_pk_file, const char *mcl_pk_file) {
+    if (!alt_pk_file || !mcl_pk_file) return fail(ZK_ERR_ARG, "null argument");
+    FullKey k;
+    ZK_TRY(full_load(alt_pk_file, ZK_CODEC_ALT_BN128, k));
+    bool ok = through_decimal(k.alpha_g1) && through_decimal(k.beta_g1) && through_decimal(k.beta_g2) && through_decimal(k.delta_g1) && through_decimal(k.delta_g2);
+    for (auto &p : k.A) ok = ok && through_decimal(p);
+    for (auto &p : k.Bg) ok = ok && through_decimal(p);
+    for (auto &p : k.Bh) ok = ok && through_decimal(p);
+    for (auto &p : k.H) ok = ok && through_decimal(p);
+    for (auto &p : k.L) ok = ok && through_decimal(p);
+    if (!ok) return fail(ZK_ERR_FORMAT, "coordinate did not survive the decimal round trip");
+    return full_save(mcl_pk_file, ZK_CODEC_MCL_BN128, k);
+}
+
+// pk_mcl2nozk (src/export.cpp:399-408) = loadFromFile<full key> + the nozk conversion of hpp:209-233
+extern "C" int zk_pk_mcl2nozk(const char *mcl_pk_file, const char *nozk_pk_file) {
+    if (!mcl_pk_file || !nozk_pk_file) return fail(ZK_ERR_ARG, "null argument");
+    FullKey k;
+    ZK_TRY(full_load(mcl_pk_file, ZK_CODEC_MCL_BN128, k));
+    zk_pk pk;
+    pk.alpha_g1 = k.alpha_g1; pk.beta_g1 = k.beta_g1; pk.beta_g2 = k.beta_g2; pk.delta_g1 = k.delta_g1; pk.delta_g2 = k.delta_g2;
+    pk.a_domain = (uint32_t)k.A.size();
+    for (size_t i = 0; i < k.A.size(); i++) if (!G1::is_inf(k.A[i])) { pk.a_idx.push_back((uint32_t)i); pk.a_val.push_back(k.A[i]); }
+    pk.b_domain = k.b_domain; pk.b_idx = k.b_idx; pk.b_val = k.Bg;
+    pk.H = k.H; pk.L = k.L;
+    return zk_pk_save_raw(&pk, nozk_pk_file, ZK_CODEC_MCL_BN128);
 }
 
 // ================================================================ context
@@ -522,10 +617,20 @@ static int upload_witness(zk_ctx *c, const uint64_t *witness, int canonical) {
 static void store_xyzz(uint64_t *dst, const G1::XYZZ &p) { memcpy(dst, &p, sizeof(p)); }
 static void store_xyzz(uint64_t *dst, const G2::XYZZ &p) { memcpy(dst, &p, sizeof(p)); }
 
+static int prove_enqueue(zk_ctx *c, const uint64_t *witness, int canonical);
 static int prove_submit_impl(zk_ctx *c, const uint64_t *witness, int canonical) {
     if (!c || !witness) return fail(ZK_ERR_ARG, "null argument");
     if (c->in_flight) return fail(ZK_ERR_ARG, "a proof is already in flight on this context (collect it first)");
     ZK_TRY(use_device(c->device));
+    const int rc = prove_enqueue(c, witness, canonical);
+    if (rc != ZK_OK) {      // part of the proof may be queued: drain it so that the next submit cannot overwrite buffers still in use
+        hipStreamSynchronize(c->s_main); hipStreamSynchronize(c->s_a); hipStreamSynchronize(c->s_b); hipStreamSynchronize(c->s_l);
+        return rc;
+    }
+    c->in_flight = true;
+    return ZK_OK;
+}
+static int prove_enqueue(zk_ctx *c, const uint64_t *witness, int canonical) {
     ZK_TRY(upload_witness(c, witness, canonical));
     // One in-order stream carries every machine-filling kernel (sorts, accumulations, the H pipeline) so that
     // none of them is stretched by contention; the low-parallelism bucket reductions ("tails") of the B-, A-
@@ -551,7 +656,6 @@ static int prove_submit_impl(zk_ctx *c, const uint64_t *witness, int canonical) 
     ZK_HIP(hipEventRecord(c->ev_h, m));
     ZK_TRY(c->mH.enqueue(c->d_t + c->rH.lo, nullptr, c->rH.n(), 0, m, m));                      // tcc:510-518
     ZK_HIP(hipEventRecord(c->ev_h1, m));
-    c->in_flight = true;
     return ZK_OK;
 }
 
@@ -652,10 +756,6 @@ extern "C" int zk_prove(zk_ctx *ctx, const uint64_t *witness, int canonical, zk_
 // ================================================================ key generation
 // r1cs_gg_ppzksnark_zok_generator (tcc:277-449) with r1cs_to_qap_instance_map_with_evaluation
 //  and the zk -> nozk conversion of hpp:209-233.
-struct zk_vk {
-    G1::Affine alpha_g1; G2::Affine beta_g2, gamma_g2, delta_g2;
-    std::vector<G1::Affine> gamma_abc;
-};
 extern "C" void zk_vk_free(zk_vk *vk) { delete vk; }
 
 namespace {
@@ -866,6 +966,7 @@ extern "C" int zk_ntt(uint64_t *data, uint32_t logm, int inverse, int coset, int
 
 extern "C" int zk_witness_map(zk_ctx *c, const uint64_t *witness, int canonical, uint64_t *h_out) {
     if (!c || !witness || !h_out) return fail(ZK_ERR_ARG, "null argument");
+    if (c->in_flight) return fail(ZK_ERR_ARG, "a proof is in flight on this context (collect it first): its witness and H buffers are in use");
     ZK_TRY(use_device(c->device));
     ZK_TRY(upload_witness(c, witness, canonical));
     ZK_TRY(enqueue_compute_h(c));

@@ -56,8 +56,8 @@ class ZkTimings(C.Structure):
 
 EXPORTS = [
     "zk_version", "zk_strerror", "zk_last_error", "zk_device_count",
-    "zk_pk_load_raw", "zk_pk_save_raw", "zk_pk_from_bellman_json", "zk_pk_bellman2ethsnarks", "zk_pk_from_parts", "zk_pk_sizes", "zk_pk_part", "zk_pk_free",
-    "zk_keygen", "zk_vk_to_json", "zk_vk_free",
+    "zk_pk_load_raw", "zk_pk_save_raw", "zk_pk_from_bellman_json", "zk_pk_bellman2ethsnarks", "zk_pk_alt2mcl", "zk_pk_mcl2nozk", "zk_pk_from_parts", "zk_pk_sizes", "zk_pk_part", "zk_pk_free",
+    "zk_keygen", "zk_vk_to_json", "zk_vk_from_json", "zk_proof_from_json", "zk_vk_free",
     "zk_domain_size", "zk_ctx_create", "zk_ctx_destroy",
     "zk_prove", "zk_prove_timed", "zk_prove_partial", "zk_prove_partial_timed", "zk_prove_combine", "zk_prove_submit", "zk_prove_collect", "zk_proof_to_json",
     "zk_verify",
@@ -186,6 +186,21 @@ def pk_bellman2ethsnarks(bellman_pk_file, pk_file):
     return True
 
 
+CODEC_ALT_BN128, CODEC_MCL_BN128 = 0, 1     # include/zkhip.h; the MCL element layout is inferred (parity unpinned)
+
+
+def pk_alt2mcl(alt_pk_file, mcl_pk_file):
+    """pk_alt2mcl (src/export.cpp:352-397) over the full proving-key stream."""
+    _check(load_library(_lib_path_loaded).zk_pk_alt2mcl(os.fsencode(alt_pk_file), os.fsencode(mcl_pk_file)))
+    return True
+
+
+def pk_mcl2nozk(mcl_pk_file, nozk_pk_file):
+    """pk_mcl2nozk (src/export.cpp:399-408)."""
+    _check(load_library(_lib_path_loaded).zk_pk_mcl2nozk(os.fsencode(mcl_pk_file), os.fsencode(nozk_pk_file)))
+    return True
+
+
 class VerificationKey:
     """r1cs_gg_ppzksnark_zok_verification_key (hpp:296-350); only what keygen hands out."""
 
@@ -210,6 +225,25 @@ class VerificationKey:
             self.close()
         except Exception:
             pass
+
+
+def vk_from_json(text):
+    """vk_from_json (src/import.cpp:195-223): hex / decimal strings, Fq2 as [c1, c0]."""
+    h = C.c_void_p()
+    _check(load_library(_lib_path_loaded).zk_vk_from_json(text.encode(), C.byref(h)))
+    return VerificationKey(h)
+
+
+def proof_from_json(text):
+    """proof_from_json (src/import.cpp:161-192): (ZkProof, canonical inputs[n, 4])."""
+    lib = load_library(_lib_path_loaded)
+    proof, n = ZkProof(), C.c_uint32(0)
+    rc = lib.zk_proof_from_json(text.encode(), C.byref(proof), None, C.c_uint32(0), C.byref(n))
+    if rc != 0 and n.value == 0:
+        _check(rc)
+    inputs = np.zeros((n.value, 4), dtype=np.uint64)
+    _check(lib.zk_proof_from_json(text.encode(), C.byref(proof), _p64(inputs) if n.value else None, C.c_uint32(n.value), C.byref(n)))
+    return proof, inputs
 
 
 def _csr_structs(r1cs, keep):

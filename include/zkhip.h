@@ -8,6 +8,7 @@
  *                          operator>>(istream&, pk_nozk&)                    r1cs_gg_ppzksnark_zok.tcc:124-143
  *   zk_pk_save_raw      <- writeToFile<ProvingKeyT> / operator<<             src/utils.hpp:166-173, tcc:108-122
  *   zk_pk_from_bellman_json / zk_pk_bellman2ethsnarks <- pk_bellman2ethsnarks + readG1/readG2   src/export.cpp:223-328
+ *   zk_pk_alt2mcl / zk_pk_mcl2nozk <- pk_alt2mcl / pk_mcl2nozk                src/export.cpp:330-408
  *   zk_pk_from_parts    <- r1cs_gg_ppzksnark_zok_proving_key_nozk ctor       r1cs_gg_ppzksnark_zok.hpp:171-233
  *   zk_ctx_create       <- ProverContext<ppT>(pk) + get_domain(pb, pk, cfg)  hpp:279-291, src/stubs.cpp:61-75
  *   zk_prove            <- r1cs_gg_ppzksnark_zok_prover(ctx, pb.values)      tcc:451-550 (via prove(), stubs.cpp:42-47)
@@ -16,6 +17,7 @@
  *   zk_keygen           <- r1cs_gg_ppzksnark_zok_generator + nozk conversion  tcc:277-449, hpp:209-233
  *                          (stub_genkeys_from_pb, src/stubs.cpp:77-87)
  *   zk_vk_to_json       <- vk2json                                            src/export.cpp:124-145
+ *   zk_vk_from_json / zk_proof_from_json <- vk_from_json / proof_from_json   src/import.cpp:161-223
  *   zk_verify / ethsnarks_verify <- stub_verify / ethsnarks_verify          src/stubs.cpp:16-33, src/verify_dll.cpp:3-10
  *
  * Plain C types only.  Field elements are 4 x u64 little-endian limbs; "Montgomery" means the
@@ -47,7 +49,10 @@ extern "C" {
 #define ZK_ERR_NODEVICE 8
 #define ZK_ERR_BUFFER 9    /* output buffer too small */
 
-#define ZK_CODEC_ALT_BN128 0   /* upstream libff layout; the only codec validated so far */
+#define ZK_CODEC_ALT_BN128 0   /* upstream libff alt_bn128 stream layout */
+#define ZK_CODEC_MCL_BN128 1   /* the reference's default curve build (CMakeLists.txt:47-54); its element encoding lives in the
+                                  absent libff fork and is INFERRED (same flag + raw Montgomery coordinates as ALT_BN128):
+                                  parity unpinned -- the reference holds no key file (open risk) */
 
 typedef struct zk_pk zk_pk;
 typedef struct zk_vk zk_vk;
@@ -108,6 +113,11 @@ int zk_pk_save_raw(const zk_pk *pk, const char *path, int codec);
  * zk_pk_bellman2ethsnarks writes the `.raw` file the reference's converter writes */
 int zk_pk_from_bellman_json(const char *json_path, zk_pk **out);
 int zk_pk_bellman2ethsnarks(const char *bellman_pk_json, const char *pk_raw);
+/* the reference's offline converters over the FULL (zero-knowledge) proving key stream (tcc:53-90):
+ * pk_alt2mcl (src/export.cpp:352-397: every coordinate goes through its decimal string) and
+ * pk_mcl2nozk (src/export.cpp:399-408: nozk conversion of hpp:209-233, written with the MCL codec) */
+int zk_pk_alt2mcl(const char *alt_pk_file, const char *mcl_pk_file);
+int zk_pk_mcl2nozk(const char *mcl_pk_file, const char *nozk_pk_file);
 int zk_pk_from_parts(const uint64_t *alpha_g1, const uint64_t *beta_g1, const uint64_t *beta_g2,
                      const uint64_t *delta_g1, const uint64_t *delta_g2,
                      uint32_t a_domain, uint32_t nA, const uint32_t *a_idx, const uint64_t *a_val,
@@ -126,6 +136,11 @@ void zk_pk_free(zk_pk *pk);
 int zk_keygen(const zk_csr *A, const zk_csr *B, const zk_csr *C, uint32_t nC, uint32_t nIn, uint32_t V,
               const uint64_t toxic_canon[20], int device, zk_pk **pk_out, zk_vk **vk_out);
 int zk_vk_to_json(const zk_vk *vk, char *buf, size_t cap, size_t *len);
+/* vk_from_json / proof_from_json (src/import.cpp:161-223): "0x" hex or decimal strings, Fq2 as [c1, c0].
+ * zk_proof_from_json: the proof's public inputs come back canonical (4 x u64 each) in inputs_canon[0 .. *n_inputs);
+ * ZK_ERR_BUFFER if cap is too small (*n_inputs still set), ZK_ERR_FORMAT on malformed text or coordinates >= q */
+int zk_vk_from_json(const char *vk_json, zk_vk **out);
+int zk_proof_from_json(const char *proof_json, zk_proof *out, uint64_t *inputs_canon, uint32_t cap, uint32_t *n_inputs);
 void zk_vk_free(zk_vk *vk);
 
 /* ---- prover context: uploads bases + CSR once, builds domain tables, owns all scratch.

@@ -187,6 +187,20 @@ def keygen(r, seed=None, toxic=None):
     return PK(pk), VK(vk)
 
 
+def pk_from_parts(parts):
+    """oracle proving key from the arrays of a key (e.g. ethsnarks_amd.prover.ProvingKey.parts())"""
+    keep = {k: np.ascontiguousarray(v) for k, v in parts.items() if hasattr(v, "dtype")}
+    u64 = lambda a: _p64(np.ascontiguousarray(a, dtype=np.uint64))
+    u32 = lambda a: _p32(np.ascontiguousarray(a, dtype=np.uint32))
+    h = C.c_void_p()
+    rc = lib().orc_pk_from_parts(u64(keep["alpha_g1"]), u64(keep["beta_g1"]), u64(keep["beta_g2"]), u64(keep["delta_g1"]), u64(keep["delta_g2"]),
+                                 C.c_uint32(parts["a_domain"]), C.c_uint32(len(keep["a_idx"])), u32(keep["a_idx"]), u64(keep["a_val"]),
+                                 C.c_uint32(parts["b_domain"]), C.c_uint32(len(keep["b_idx"])), u32(keep["b_idx"]), u64(keep["b_val"]),
+                                 C.c_uint32(len(keep["H"])), u64(keep["H"]), C.c_uint32(len(keep["L"])), u64(keep["L"]), C.byref(h))
+    assert rc == 0
+    return PK(h)
+
+
 def read_raw(path):
     pk = C.c_void_p()
     rc = lib().orc_pk_read_raw(path.encode(), C.byref(pk))

@@ -69,3 +69,43 @@ def test_plain_c_client_links_and_verifies(tmp_path):
     assert out.returncode == 0 and "accepted" in out.stdout and "= 1048576" in out.stdout, out.stdout + out.stderr
     out = subprocess.run([exe, str(vk), str(bad)], capture_output=True, text=True)
     assert out.returncode == 1 and "rejected" in out.stdout
+
+
+@pytest.mark.skipif(not os.path.exists(LIB), reason="libzkhip.so not built (run __graft_entry__.build())")
+def test_json_readers_and_writers_on_the_reference_static_triple():
+    """host-only entry points, no GPU needed: the reference's static proof / key text (test/test_verify.py:10-12) goes
+    through zk_proof_from_json / zk_vk_from_json and comes back from zk_proof_to_json / zk_vk_to_json token for token"""
+    import json
+    from ethsnarks_amd import prover
+    prover._lib = None; prover._lib_path_loaded = None
+    prover.load_library()
+    d = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_static_triple.json")))
+    flat = lambda x: [x] if isinstance(x, str) else [t for y in x for t in flat(y)]
+    proof, inputs = prover.proof_from_json(json.dumps(d["proof"]))
+    text = prover.proof_to_json(proof, inputs, canonical=True)
+    assert json.loads(text) == d["proof"]
+    assert re.findall(r'"(0x[0-9a-f]+)"', text) == flat([d["proof"][k] for k in ("A", "B", "C", "input")])
+    vk = prover.vk_from_json(json.dumps(d["vk"]))
+    assert json.loads(vk.to_json()) == d["vk"]
+    assert re.findall(r'"(0x[0-9a-f]+)"', vk.to_json()) == flat([d["vk"][k] for k in ("alpha", "beta", "gamma", "delta", "gammaABC")])
+    # decimal strings are accepted as well (parse_bigint, src/import.hpp:15-33); coordinates >= q are not
+    dec = json.loads(json.dumps(d["proof"]))
+    dec["A"] = [str(int(t, 16)) for t in dec["A"]]
+    p2, _ = prover.proof_from_json(json.dumps(dec))
+    assert bytes(p2) == bytes(proof)
+    bad = dict(d["proof"], A=["0x" + "f" * 64, d["proof"]["A"][1]])
+    with pytest.raises(prover.ZkError) as e:
+        prover.proof_from_json(json.dumps(bad))
+    assert e.value.code == 3
+    prover._lib = None; prover._lib_path_loaded = None
+
+
+@pytest.mark.skipif(not os.path.exists(LIB), reason="libzkhip.so not built (run __graft_entry__.build())")
+def test_unknown_raw_codec_is_rejected(tmp_path):
+    from ethsnarks_amd import prover
+    prover._lib = None; prover._lib_path_loaded = None
+    prover.load_library()
+    with pytest.raises(prover.ZkError) as e:
+        prover.load_proving_key(str(tmp_path / "pk.raw"), codec=77)
+    assert e.value.code == 1
+    prover._lib = None; prover._lib_path_loaded = None

@@ -169,6 +169,51 @@ def test_errors(hip, oracle, tmp_path):
     assert e.value.code == 2
 
 
+def test_config1_mimc_hash_preimage_11_words(hip, oracle):
+    """BASELINE config 1's workload on the HIP path: MiMC-e7 Miyaguchi-Preneel hash preimage over 11 message words
+    (the in-tree substitute of the SHA256 hashpreimage gadget), 4 016 constraints, m = 2^12.  GPU keygen ==
+    oracle keygen, proof byte-identical to the oracle, accepted by zk_verify and by the pinned big-int verifier."""
+    import pyref
+    from ethsnarks_amd import gadgets as G
+    r, w, _ = G.mimc_preimage_circuit(11)
+    assert r.domain_size == 1 << 12
+    wm = F.fr_to_mont(w)
+    pk, vk = hip.keygen(r, seed=11)
+    pk_o, vk_o = oracle.keygen(r, seed=11)
+    assert vk.to_json() == vk_o.to_json()
+    ctx = hip.ProverContext(pk, r)
+    got = hip.prove(ctx, wm)
+    expect, _ = oracle.prove(pk_o, r, wm)
+    assert got == expect
+    assert hip.stub_verify(vk.to_json(), got)
+    assert pyref.verify(json.loads(vk.to_json()), json.loads(got))
+    bad = json.loads(got); bad["A"], bad["C"] = bad["C"], bad["A"]
+    assert not hip.stub_verify(vk.to_json(), json.dumps(bad))
+    ctx.close()
+
+
+def test_json_writers_reproduce_the_reference_static_triple(hip):
+    """The JSON WRITERS on text the reference holds (test/test_verify.py:10-12): the static proof and key are parsed into
+    zk_proof / zk_vk (zk_proof_from_json / zk_vk_from_json = proof_from_json / vk_from_json, src/import.cpp:161-223) and
+    written back by zk_proof_to_json / zk_vk_to_json (src/export.cpp:20-33,56-145): every "0x..." token (63-digit values
+    included: no zero padding, lowercase) and the [c1, c0] nesting must come out as the fixture has them."""
+    import os, re
+    from helpers import GOLDEN
+    d = json.load(open(os.path.join(GOLDEN, "ref_static_triple.json")))
+    proof, inputs = hip.proof_from_json(json.dumps(d["proof"]))
+    text = hip.proof_to_json(proof, inputs, canonical=True)
+    assert json.loads(text) == d["proof"]
+    flat = lambda x: [x] if isinstance(x, str) else [t for y in x for t in flat(y)]
+    assert re.findall(r'"(0x[0-9a-f]+)"', text) == flat([d["proof"][k] for k in ("A", "B", "C", "input")])
+    assert text.startswith('{\n "A" :["0x') and '],\n "B"  :[["0x' in text and '"],\n ["0x' in text and '],\n "input" :["0x' in text
+    vk = hip.vk_from_json(json.dumps(d["vk"]))
+    vtext = vk.to_json()
+    assert json.loads(vtext) == d["vk"]
+    assert re.findall(r'"(0x[0-9a-f]+)"', vtext) == flat([d["vk"][k] for k in ("alpha", "beta", "gamma", "delta", "gammaABC")])
+    assert any(len(t) < 66 for t in flat(d["vk"])) and any(len(t) < 66 for t in flat(d["proof"]))      # the fixture does hold short values
+    assert hip.stub_verify(vtext, text)
+
+
 def test_config4_merkle_membership_depth29(hip, oracle):
     """BASELINE config 4: merkle_path_authenticator<MiMC_e7_hash_gadget>, depth 29, 21 345 constraints, m = 2^15;
     key from the GPU generator, proof byte-identical to the oracle and accepted by the pinned verifier"""
@@ -268,16 +313,7 @@ def test_config3_chain_2pow20_headline(hip, oracle):
     ctx = hip.ProverContext(pk, r)
     got = hip.prove(ctx, wm)
     ctx.close()
-    import ctypes as C
-    parts = pk.parts()
-    h = C.c_void_p()
-    u64 = lambda a: oracle._p64(np.ascontiguousarray(a, dtype=np.uint64))
-    u32 = lambda a: oracle._p32(np.ascontiguousarray(a, dtype=np.uint32))
-    assert oracle.lib().orc_pk_from_parts(u64(parts["alpha_g1"]), u64(parts["beta_g1"]), u64(parts["beta_g2"]), u64(parts["delta_g1"]), u64(parts["delta_g2"]),
-                                          C.c_uint32(parts["a_domain"]), C.c_uint32(len(parts["a_idx"])), u32(parts["a_idx"]), u64(parts["a_val"]),
-                                          C.c_uint32(parts["b_domain"]), C.c_uint32(len(parts["b_idx"])), u32(parts["b_idx"]), u64(parts["b_val"]),
-                                          C.c_uint32(len(parts["H"])), u64(parts["H"]), C.c_uint32(len(parts["L"])), u64(parts["L"]), C.byref(h)) == 0
-    expect, _ = oracle.prove(oracle.PK(h), r, wm)
+    expect, _ = oracle.prove(oracle.pk_from_parts(pk.parts()), r, wm)
     assert got == expect
     shards = []
     for k in range(4):
@@ -292,8 +328,8 @@ def test_config5_size_2pow22_sharded_over_eight(hip, oracle):
     """BASELINE config 5's size (2^22 constraints, the reference's largest named case) on the one GPU of the test box: the
     key comes from zk_keygen and passes the product's own verifier through the proof, and the 8-way base-range sharding
     north_star describes (one shard per GPU, 640-byte partials folded in rank order) reproduces the unsharded proof byte for
-    byte -- the eight shards run one after the other here.  The CPU oracle is not run at this size (15 s per proof on 16
-    cores is spent in config 3's test instead); the size-independent checks are sharding invariance and verification."""
+    byte -- the eight shards run one after the other here.  The CPU oracle proves the same key and witness at full size too
+    (about 15 s on the box's 16 cores): byte-identical JSON."""
     logm = 22
     r, w = R.synthetic_chain((1 << logm) - 2, 1)
     wm = F.fr_to_mont(w)
@@ -302,6 +338,8 @@ def test_config5_size_2pow22_sharded_over_eight(hip, oracle):
     got = hip.prove(ctx, wm)
     ctx.close()
     assert hip.stub_verify(vk.to_json(), got)
+    expect, _ = oracle.prove(oracle.pk_from_parts(pk.parts()), r, wm)        # the oracle at 2^22
+    assert got == expect
     d = json.loads(got)
     d["input"][0] = d["input"][0][:-1] + ("0" if d["input"][0][-1] != "0" else "1")      # another public input
     assert not hip.stub_verify(vk.to_json(), json.dumps(d))

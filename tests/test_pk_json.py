@@ -120,3 +120,62 @@ def test_library_bellman_import_and_raw_conversion(key, tmp_path):
     with pytest.raises(prover.ZkError):
         prover.load_bellman_proving_key(jpath)
     prover._lib = None; prover._lib_path_loaded = None
+
+
+def _full_key_stream(P):
+    """test-side writer of the FULL (zero-knowledge) proving key stream of r1cs_gg_ppzksnark_zok.tcc:53-66 from a nozk
+    key: A_query gets its zero entries back, every B_query value becomes a knowledge commitment (g = the G2 value, h = a
+    G1 point made up here: beta_g1).  Point = '0' + raw Montgomery coordinates, infinity = '1' + (0, one)."""
+    one = np.ascontiguousarray(F.fq_to_mont([1])).reshape(-1)
+
+    def pt(raw, nlimb):
+        raw = np.ascontiguousarray(raw, dtype=np.uint64).reshape(-1)
+        if not raw.any():
+            img = np.zeros(nlimb, dtype=np.uint64); img[nlimb // 2:nlimb // 2 + 4] = one
+            return b"1" + img.tobytes()
+        return b"0" + raw.tobytes()
+    out = [pt(P["alpha_g1"], 8), pt(P["beta_g1"], 8), pt(P["beta_g2"], 16), pt(P["delta_g1"], 8), pt(P["delta_g2"], 16)]
+    n = int(P["a_domain"])
+    A = np.zeros((n, 8), dtype=np.uint64)
+    A[np.asarray(P["a_idx"], dtype=np.int64)] = P["a_val"]
+    out.append(b"%d\n" % n + b"".join(pt(A[i], 8) for i in range(n)))
+    out.append(b"%d\n%d\n" % (int(P["b_domain"]), len(P["b_idx"])) + b"".join(b"%d\n" % int(i) for i in P["b_idx"]) + b"%d\n" % len(P["b_idx"]))
+    out.append(b"".join(pt(P["b_val"][i], 16) + pt(P["beta_g1"], 8) for i in range(len(P["b_idx"]))))
+    for q in ("H", "L"):
+        out.append(b"%d\n" % len(P[q]) + b"".join(pt(P[q][i], 8) for i in range(len(P[q]))))
+    return b"".join(out)
+
+
+@pytest.mark.skipif(not os.path.exists(LIB), reason="libzkhip.so not built (run __graft_entry__.build())")
+def test_mcl_codec_and_the_alt2mcl_mcl2nozk_converters(key, tmp_path):
+    """ZK_CODEC_MCL_BN128 (the reference's default curve build; element layout INFERRED, parity unpinned: the reference holds
+    no key file) and the offline converters pk_alt2mcl / pk_mcl2nozk (src/export.cpp:330-408): a full key goes alt -> mcl
+    through the decimal strings of every coordinate, mcl -> nozk drops A's zeros and B's G1 halves, and the nozk key read
+    back with the MCL codec is the key the chain started from."""
+    from ethsnarks_amd import prover
+    prover._lib = None; prover._lib_path_loaded = None
+    prover.load_library()
+    r, pk = key
+    P = pk.parts()
+    alt, mcl, nozk, ref = (str(tmp_path / n) for n in ("full_alt.raw", "full_mcl.raw", "nozk_mcl.raw", "nozk_oracle.raw"))
+    open(alt, "wb").write(_full_key_stream(P))
+    assert prover.pk_alt2mcl(alt, mcl) is True
+    assert open(mcl, "rb").read() == open(alt, "rb").read()      # the decimal path lands on the inferred layout's bytes
+    assert prover.pk_mcl2nozk(mcl, nozk) is True
+    pk.write_raw(ref)
+    assert open(nozk, "rb").read() == open(ref, "rb").read()
+    back = prover.load_proving_key(nozk, codec=prover.CODEC_MCL_BN128)
+    G = back.parts()
+    for k, v in P.items():
+        assert np.array_equal(G[k], v) if hasattr(v, "dtype") else G[k] == v, k
+    rt = str(tmp_path / "rt.raw")
+    back.save_raw(rt, codec=prover.CODEC_MCL_BN128)
+    assert open(rt, "rb").read() == open(ref, "rb").read()
+    with pytest.raises(prover.ZkError) as e:
+        back.save_raw(rt, codec=2)
+    assert e.value.code == 1
+    open(alt, "wb").write(_full_key_stream(P)[:-7])              # truncated stream: an error code, not an abort
+    with pytest.raises(prover.ZkError) as e:
+        prover.pk_alt2mcl(alt, mcl)
+    assert e.value.code == 3
+    prover._lib = None; prover._lib_path_loaded = None
