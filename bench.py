@@ -5,22 +5,27 @@
 
 A "step" is one full proof (witness -> QAP coefficients -> four multi-exponentiations -> proof) of the
 synthetic chain R1CS of SURVEY 8(d) with nC = 2^20 - 2 constraints (domain m = 2^20 exactly), nIn = 1,
-on a real proving key produced by this library's GPU key generator (seeded toxic waste), key and
-constraint system resident in HBM, witness handed over as a host buffer (its 33.5 MB upload is inside the
-timed region).  N > 1 (launched by torch.distributed.run, one rank per GPU): proofs are independent units, so
-the headline leg runs one prover per GPU with no data-path collective ("weak" scaling, value = all proofs of
-all ranks / max-over-ranks time).  The MSM-sharded leg of north_star / BASELINE config 5 is timed too and
-reported under "msm_sharded": the base ranges of the key are split over the ranks, every rank proves its
-shard, the 640-byte partial results are exchanged with one RCCL all-gather and folded in rank order
-("strong": the GPUs share each proof; the witness -> H pipeline is replicated).  --mode shard makes that
-leg the headline instead.  --inflight K (default 3) keeps K
-prover contexts per GPU busy through the asynchronous zk_prove_submit / zk_prove_collect pair, so the next
-proof's witness upload and sort overlap the bucket-reduction tails of the current one; every step still
-completes a full proof, and --inflight 1 gives the one-proof-at-a-time latency figure.
+on a real proving key produced by this library's GPU key generator (seeded toxic waste).  Key, constraint
+system AND witness are resident in HBM when the timed region starts (`value`); the rate with the witness
+handed over as a host buffer -- its 33.5 MB upload inside the timed region -- is measured on a short
+second leg and reported under "host_witness" (never as `value`).
 
-Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (k_msm_accumulate over G2,
-the B-query); `cpu_baseline` is the CPU oracle (oracle/, a restatement of the reference prover --
-libsnark itself cannot be built offline) timed on this host's cores on one proof of the same key.
+N > 1 (launched by torch.distributed.run, one rank per GPU): proofs are independent units, so the
+headline leg runs one prover per GPU with no data-path collective ("weak" scaling, value = all proofs of
+all ranks / max-over-ranks time).  The MSM-sharded prover of north_star / BASELINE config 5 is timed too
+and reported under "msm_sharded" (same circuit: the GPUs share each proof) and "msm_sharded_2p22"
+(config 5's size, 2^22 constraints): the base ranges of the key are split over the ranks, every rank
+proves its shard, the 640-byte partial results are exchanged with ONE RCCL all-gather on device buffers
+and folded in rank order ("strong"; the witness -> H pipeline is replicated).  --mode shard makes the
+sharded leg the headline instead.  --inflight K (default 3) keeps K prover contexts per GPU busy through
+the asynchronous zk_prove_submit / zk_prove_collect pair, so the next proof's sorts overlap the
+bucket-reduction tails of the current one; every step still completes a full proof, and --inflight 1
+gives the one-proof-at-a-time latency figure.
+
+Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (k_msm_accumulate over G2, the
+B-query) from HIP events recorded around it on its own stream in this run; `cpu_baseline` is the CPU
+oracle (oracle/, a restatement of the reference prover -- libsnark itself cannot be built offline) timed
+on this host's cores.
 """
 import argparse
 import json
@@ -33,7 +38,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 MAD_LANE_OPS_PER_CLK_CU = 43.4  # measured v_mad_u64_u32 rate, tools/microbench (profiles/r01_microbench.txt)
-MADS_PER_G2_MADD = 6 * 400 + 2 * 272 + 656   # = 3600, see the valu block below
+MADS_PER_G2_MADD = 6 * 400 + 2 * 272 + 656   # = 3600: 6 Fq2 products (2 x (2 x 64 + 72)), 2 Fq2 squarings (2 x 136), one 2-term Fq2 dot product (2 x (4 x 64 + 72))
+PMC_PROFILE = os.path.join("profiles", "r02_pmc_traffic.json")
 
 
 def main():
@@ -48,10 +54,13 @@ def main():
                          "(real MiMC circuits from ethsnarks_amd.gadgets; latency-sized, not the headline)")
     ap.add_argument("--multi-exp-c", type=int, default=0)
     ap.add_argument("--inflight", type=int, default=3,
-                    help="prover contexts kept in flight per GPU (1 = one synchronous proof at a time; 2 overlaps the "
-                         "next proof's upload/sort with the current proof's bucket-reduction tails)")
+                    help="prover contexts kept in flight per GPU (1 = one synchronous proof at a time)")
+    ap.add_argument("--witness", choices=["resident", "host"], default="resident",
+                    help="where the witness lives when the timed region starts (`value` is quoted on resident)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-logm", type=int, default=0, help="size of the CPU-baseline sample (default: same as --logm)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary legs (host-witness rate, sharded legs, kernel sum)")
+    ap.add_argument("--cpu-1t-logm", type=int, default=16, help="size of the one-thread CPU sample (a full 2^20 proof takes a minute on one core)")
+    ap.add_argument("--shard-logm", type=int, default=22, help="size of the config-5 sharded leg at N > 1")
     args = ap.parse_args()
 
     import numpy as np
@@ -78,29 +87,32 @@ def main():
         assert dist.get_world_size() == world, "--gpus must equal WORLD_SIZE"
     else:
         torch.cuda.set_device(0)
-    dev = torch.device("cpu") if (rehearse and world > 1) else torch.device("cuda", local_rank)
+    gloo = rehearse and world > 1
 
     P.load_library()                                   # raises if libzkhip.so is missing: no CPU fallback
-    logm = args.logm
-    nC = (1 << logm) - 2
-    t0 = time.time()
-    if args.workload == "chain":
-        r1cs, w_ints = R.synthetic_chain(nC, 1)
-        workload = "synthetic chain R1CS (SURVEY 8d), nC=2^%d-2=%d, nIn=1, V=%d, domain m=2^%d; real seeded Groth16 key" % (logm, nC, r1cs.V, logm)
-    else:
-        from ethsnarks_amd import gadgets as G
-        r1cs, w_ints, _ = G.merkle_membership_circuit(29) if args.workload == "merkle29" else G.mimc_preimage_circuit(11)
-        nC = r1cs.nC
-        logm = r1cs.domain_size.bit_length() - 1
-        workload = "%s (BASELINE config %s): nC=%d, nIn=%d, V=%d, domain m=2^%d; real seeded Groth16 key" % (
-            "merkle_path_authenticator<MiMC_e7_hash_gadget> depth 29" if args.workload == "merkle29" else "MiMC-e7 hash preimage, 11 words",
-            "4" if args.workload == "merkle29" else "1", nC, r1cs.nIn, r1cs.V, logm)
-    wm = F.fr_to_mont(w_ints)
-    t_circuit = time.time() - t0
-    t0 = time.time()
-    pk, vk = P.keygen(r1cs, seed=R.SEED_DEFAULT, device=local_rank)   # same seeded key on every rank
-    t_keygen = time.time() - t0
-    m = r1cs.domain_size
+    devinfo = P.device_info(local_rank)
+
+    def make_workload(workload, logm):
+        t0 = time.time()
+        if workload == "chain":
+            nC = (1 << logm) - 2
+            r1cs, w_ints = R.synthetic_chain(nC, 1)
+            name = "synthetic chain R1CS (SURVEY 8d), nC=2^%d-2=%d, nIn=1, V=%d, domain m=2^%d; real seeded Groth16 key" % (logm, nC, r1cs.V, logm)
+        else:
+            from ethsnarks_amd import gadgets as G
+            r1cs, w_ints, _ = G.merkle_membership_circuit(29) if workload == "merkle29" else G.mimc_preimage_circuit(11)
+            name = "%s (BASELINE config %s): nC=%d, nIn=%d, V=%d, domain m=2^%d; real seeded Groth16 key" % (
+                "merkle_path_authenticator<MiMC_e7_hash_gadget> depth 29" if workload == "merkle29" else "MiMC-e7 hash preimage, 11 words",
+                "4" if workload == "merkle29" else "1", r1cs.nC, r1cs.nIn, r1cs.V, r1cs.domain_size.bit_length() - 1)
+        wm = F.fr_to_mont(w_ints)
+        t_circuit = time.time() - t0
+        t0 = time.time()
+        pk, vk = P.keygen(r1cs, seed=R.SEED_DEFAULT, device=local_rank)   # same seeded key on every rank
+        return r1cs, wm, pk, name, t_circuit, time.time() - t0
+
+    r1cs, wm, pk, workload, t_circuit, t_keygen = make_workload(args.workload, args.logm)
+    nC, m = r1cs.nC, r1cs.domain_size
+    logm = m.bit_length() - 1
 
     def sync():
         torch.cuda.synchronize()
@@ -108,25 +120,32 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_leg(shard):
-        """W warm-up + K timed proofs in one parallelisation; returns (proofs/s, elapsed, kernel ms list, timings, json)"""
+    from ethsnarks_amd.sharded import ShardedProver
+
+    def run_leg(pk, r1cs, wm, shard, steps, warmup, witness):
+        """`warmup` untimed + `steps` timed proofs in one parallelisation"""
         ctxs = [P.ProverContext(pk, r1cs, multi_exp_c=args.multi_exp_c, device=local_rank,
                                 shard_rank=rank if shard else 0, shard_count=world if shard else 1)
                 for _ in range(max(1, args.inflight))]
-        gather_buf = torch.empty((world, 640), dtype=torch.uint8, device=dev) if shard else None
+        d_w = torch.from_numpy(np.ascontiguousarray(wm).view(np.int64).copy()).cuda() if witness == "resident" else None
+        sharded = [ShardedProver(c, dist, torch.device("cuda", local_rank)) for c in ctxs] if (shard and not gloo) else None
+        gather_buf = torch.empty((world, 640), dtype=torch.uint8) if (shard and gloo) else None
         acc_b, pending, state = [], [], {"t": {}}
 
         def finish(slot):
-            """collect slot's proof; sharded: one RCCL all-gather of the 640-byte partials, folded in rank order"""
-            part, tm = ctxs[slot].collect()
-            if shard:
-                mine = torch.from_numpy(part.view(np.uint8).copy()).to(dev)
-                dist.all_gather_into_tensor(gather_buf.view(-1), mine)
-                part = gather_buf.cpu().numpy().reshape(-1).view(np.uint64)
-            proof = ctxs[slot].prove_combine(part)
+            """collect slot's proof; sharded: one all-gather of the 640-byte partials (device buffers), folded in rank order"""
+            if shard and gloo:                                  # rehearsal on one GPU: gloo cannot see device memory
+                part, tm = ctxs[slot].collect()
+                dist.all_gather_into_tensor(gather_buf.view(-1), torch.from_numpy(part.view(np.uint8).copy()))
+                proof = ctxs[slot].prove_combine(gather_buf.numpy().reshape(-1).view(np.uint64))
+            elif shard:
+                proof, tm = sharded[slot].finish()
+            else:
+                part, tm = ctxs[slot].collect()
+                proof = ctxs[slot].prove_combine(part)
             state["t"] = tm
             acc_b.append(tm["acc_b"])
-            return P.proof_to_json(proof, wm[1:2])
+            return P.proof_to_json(proof, wm[1:1 + r1cs.nIn])
 
         def run(nsteps):
             js = None
@@ -134,56 +153,97 @@ def main():
                 if len(pending) == len(ctxs):
                     js = finish(pending.pop(0))
                 slot = i % len(ctxs)
-                ctxs[slot].submit(wm)
+                if d_w is not None:
+                    ctxs[slot].submit_resident(d_w.data_ptr())
+                else:
+                    ctxs[slot].submit(wm)
                 pending.append(slot)
             while pending:
                 js = finish(pending.pop(0))
             return js
 
-        if args.warmup:
-            run(args.warmup)
+        if warmup:
+            run(warmup)
         acc_b.clear()
         sync()
+        n0 = P.launch_count()
         t0 = time.perf_counter()
-        js = run(args.steps)
+        js = run(steps)
         sync()
         elapsed = time.perf_counter() - t0
+        launches = (P.launch_count() - n0) / float(steps)
         if dist is not None:
-            tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if gloo else torch.device("cuda", local_rank))
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
-        proofs = args.steps * (world if (world > 1 and not shard) else 1)
+        proofs = steps * (world if (world > 1 and not shard) else 1)
+        info = ctxs[0].info()
+        ksum = None
+        if rank == 0 and not args.no_extras and not shard:
+            # one more (untimed) proof with every launch bracketed by HIP events: sum of kernel durations per proof
+            P.profile_begin()
+            ctxs[0].submit_resident(d_w.data_ptr()) if d_w is not None else ctxs[0].submit(wm)
+            ctxs[0].collect()
+            s_ms, n_l, per = P.profile_end()
+            top = sorted(per.items(), key=lambda kv: -kv[1][1])[:6]
+            ksum = {"kernel_ms_sum_one_proof_alone": round(s_ms, 3), "launches": n_l,
+                    "top": {k.strip("()"): {"calls": c, "ms": round(v, 3)} for k, (c, v) in top}}
         for c in ctxs:
             c.close()
-        return proofs / elapsed, elapsed, list(acc_b), state["t"], js
+        return {"value": proofs / elapsed, "elapsed": elapsed, "acc_b": list(acc_b), "timings": state["t"], "json": js,
+                "launches_per_proof": launches, "info": info, "kernel_sum": ksum}
 
-    # N > 1: the headline leg runs independent provers per GPU ("weak": proofs are independent units, no
-    # data-path collective); the MSM-sharded leg (north_star / config 5: base ranges over the GPUs + one RCCL
-    # all-gather of 640-byte partials per proof, "strong") is timed as well and reported under "msm_sharded".
+    # N > 1: the headline leg runs independent provers per GPU ("weak": proofs are independent units, no data-path
+    # collective); the MSM-sharded legs (north_star / config 5) are timed as well and reported under named keys.
     mode = args.mode if world > 1 else "replicas"
     shard = world > 1 and mode == "shard"
-    value, elapsed, acc_b, last_t, js = run_leg(shard)
-    nB_local = pk.nB // world if shard else pk.nB
-    sharded_extra = None
-    if world > 1 and mode == "replicas":
+    head = run_leg(pk, r1cs, wm, shard, args.steps, args.warmup, args.witness)
+    value, elapsed, acc_b, last_t, js = head["value"], head["elapsed"], head["acc_b"], head["timings"], head["json"]
+    extras = {}
+    if not args.no_extras:
+        short = max(3, min(args.steps, 10))
         try:
-            v2, e2, _, t2, js2 = run_leg(True)
-            sharded_extra = {"value": round(v2, 4), "unit": "proofs/s", "scaling": "strong", "ms_per_step": round(1e3 * e2 / args.steps, 3),
-                             "parallelism": "msm-shard%d + RCCL all-gather of 640 B partials" % world,
-                             "matches_replica_proof": js2 == js}
-        except Exception as e:                                  # the headline line must survive a failure of the extra leg
-            sharded_extra = {"error": repr(e)[:300]}
+            other = "host" if args.witness == "resident" else "resident"
+            h2 = run_leg(pk, r1cs, wm, shard, short, 2, other)
+            extras["%s_witness" % other] = {"value": round(h2["value"], 4), "unit": "proofs/s", "steps": short,
+                                           "ms_per_step": round(1e3 * h2["elapsed"] / short, 3),
+                                           "note": ("witness handed over as a host buffer: its %.1f MB H2D copy is inside the timed region (PCIe-inclusive rate)" % (32 * (r1cs.V + 1) / 1e6))
+                                                   if other == "host" else "witness resident in HBM"}
+        except Exception as e:
+            extras["other_witness"] = {"error": repr(e)[:300]}
+        if world > 1 and mode == "replicas":
+            try:
+                s2 = run_leg(pk, r1cs, wm, True, short, 2, args.witness)
+                extras["msm_sharded"] = {"value": round(s2["value"], 4), "unit": "proofs/s", "scaling": "strong", "steps": short,
+                                         "ms_per_step": round(1e3 * s2["elapsed"] / short, 3),
+                                         "parallelism": "msm-shard%d + RCCL all-gather of 640 B partials (device buffers)" % world,
+                                         "matches_replica_proof": s2["json"] == js}
+            except Exception as e:                              # the headline line must survive a failure of an extra leg
+                extras["msm_sharded"] = {"error": repr(e)[:300]}
+            if args.workload == "chain" and args.shard_logm and args.shard_logm != logm:
+                try:
+                    r5, w5, pk5, name5, _, _ = make_workload("chain", args.shard_logm)
+                    s5 = run_leg(pk5, r5, w5, True, max(3, short // 2), 1, args.witness)
+                    extras["msm_sharded_2p%d" % args.shard_logm] = {
+                        "value": round(s5["value"], 4), "unit": "proofs/s", "scaling": "strong", "steps": max(3, short // 2),
+                        "ms_per_step": round(1e3 * s5["elapsed"] / max(3, short // 2), 3), "constraints_per_sec": round(s5["value"] * r5.nC, 1),
+                        "workload": name5, "parallelism": "msm-shard%d + RCCL all-gather of 640 B partials (device buffers)" % world}
+                    pk5.close()
+                except Exception as e:
+                    extras["msm_sharded_2p%d" % args.shard_logm] = {"error": repr(e)[:300]}
 
     out = None
     if rank == 0:
+        info = head["info"]
+        nB_local = pk.nB // world if shard else pk.nB
         kern_ms = float(np.mean(acc_b)) if acc_b else float("nan")
-        W = 254 // (args.multi_exp_c or P_pick_c(nB_local)) + 1
+        W = info["B"]["W"]                                              # the windows the B-query context really uses (zk_ctx_info)
         alg_bytes = 160.0 * nB_local                                   # 128 B G2 base + 32 B scalar per pair
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-        # multiplies (v_mad_u64_u32 lane-ops) of one G2 mixed addition as the kernel computes it: 6 Fq2 products x (4 x 64 + 2 x 72)
-        # + 2 Fq2 squarings x (2 x 136) + one two-term Fq2 dot product x 2 x (4 x 64 + 72)   (bn254.hpp: Fq2::lmul / lsqr / lmul2)
         mads = float(MADS_PER_G2_MADD) * nB_local * W
+        mad_peak = MAD_LANE_OPS_PER_CLK_CU * devinfo["compute_units"] * devinfo["clock_mhz"] * 1e6
         bytes_per_proof = proof_bytes(r1cs, pk, m)
+        traffic, traffic_src = pmc_traffic("k_msm_accumulate<G2, 1>", args.workload, logm, world if shard else 1)
         out = {
             "metric": "groth16_proofs_per_sec", "value": round(value, 4), "unit": "proofs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -193,30 +253,37 @@ def main():
             "constraints_per_sec": round(value * nC, 1),
             "config": {"workload": workload,
                        "parallelism": ("msm-shard%d+allgather640B" % world) if shard else ("replicas%d" % world if world > 1 else "1gpu"),
-                       "multi_exp_c": args.multi_exp_c or P_pick_c(nB_local), "witness": "host buffer, H2D inside the timed region", "inflight": max(1, args.inflight)},
+                       "multi_exp_c": info["B"]["c"], "windows": W,
+                       "witness": "resident in HBM when the timed region starts" if args.witness == "resident" else "host buffer, H2D inside the timed region",
+                       "inflight": max(1, args.inflight), "device": devinfo},
             "roofline": {"kernel": "k_msm_accumulate<G2, 1> (B-query bucket accumulation)", "bound": "hbm",
                          "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": pmc_traffic("k_msm_accumulate<G2, 1>", world if shard else 1),
+                         "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(kern_ms, 4),
                          "note": "VALU-integer bound kernel (no dense contraction, no MFMA): see valu. traffic > algorithmic bytes by design: "
                                  "each base is read through its W window multiples (msm.hpp), trading HBM bytes for 16x fewer bucket reductions"},
             "valu": {"kernel": "k_msm_accumulate<G2, 1>", "unit": "T mad/s (v_mad_u64_u32 lane-ops)",
                      "achieved": round(mads / (kern_ms * 1e-3) / 1e12, 3) if kern_ms > 0 else 0.0,
-                     "peak": round(MAD_LANE_OPS_PER_CLK_CU * 256 * 2.4e9 / 1e12, 2),
-                     "frac": round(mads / (kern_ms * 1e-3) / (MAD_LANE_OPS_PER_CLK_CU * 256 * 2.4e9), 4) if kern_ms > 0 else 0.0,
-                     "peak_basis": "measured v_mad_u64_u32 issue rate (43.4 lane-ops/clk/CU, profiles/r01_microbench.txt) x 256 CU x 2.4 GHz; "
-                                   "the multiplies are 2/3 of the kernel's VALU issue slots, the rest are carry/fold/select instructions",
+                     "peak": round(mad_peak / 1e12, 2),
+                     "frac": round(mads / (kern_ms * 1e-3) / mad_peak, 4) if kern_ms > 0 else 0.0,
+                     "peak_basis": "measured v_mad_u64_u32 issue rate (43.4 lane-ops/clk/CU, profiles/r01_microbench.txt) x %d CU x %.1f GHz (device properties); "
+                                   "measured on MI355X the kernel's time is the SUM of its instructions' issue times (multiplies ~5.9 cycles, carry adds ~2.4: "
+                                   "tools/mulbench.cpp, DESIGN section 4), so the multiplies alone cap it at ~0.65 of this peak" % (devinfo["compute_units"], devinfo["clock_mhz"] / 1e3),
                      "mads_per_mixed_addition": MADS_PER_G2_MADD},
             "proof_hbm": {"algorithmic_bytes_per_proof": bytes_per_proof,
                           "achieved_GBps": round(bytes_per_proof * value / 1e9, 3),
                           "frac_of_peak": round(bytes_per_proof * value / 1e9 / (world * HBM_PEAK_GBPS), 6)},
             "phases_ms_last_step": {k: round(v, 3) for k, v in last_t.items()},
+            "launches_per_proof": round(head["launches_per_proof"], 1),
+            "kernel_sum": head["kernel_sum"],
             "setup_s": {"circuit": round(t_circuit, 2), "gpu_keygen": round(t_keygen, 2)},
         }
-        if sharded_extra is not None:
-            out["msm_sharded"] = sharded_extra
+        if out["kernel_sum"] is not None:
+            out["kernel_sum"]["note"] = ("HIP-event durations of every launch of one proof run alone, overlapping tails counted each; the timed steps keep %d proofs in flight, "
+                                         "so ms_per_step (%.2f) is below this sum" % (max(1, args.inflight), out["ms_per_step"]))
+        out.update(extras)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"], out["parity_vs_oracle"] = cpu_baseline(args, pk, r1cs, wm, js, logm)
+            out["cpu_baseline"], out["parity_vs_oracle"] = cpu_baseline(args, P, R, F, pk, r1cs, wm, js, logm, local_rank)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -224,22 +291,19 @@ def main():
         print(json.dumps(out), flush=True)
 
 
-def pmc_traffic(kernel, shards):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (2 x FETCH_SIZE + WRITE_SIZE, collected with
-    rocprofv3 --pmc in separate runs, tools/pmc_summary.py); valid for the unsharded 2^20 workload only."""
+def pmc_traffic(kernel, workload, logm, shards):
+    """HBM bytes per launch of `kernel` from the committed PMC passes of THIS round's kernels (rocprofv3 --pmc FETCH_SIZE and
+    --pmc WRITE_SIZE in separate runs, tools/pmc_summary.py).  Only returned when the profiled configuration is the one
+    being run (workload, domain size, unsharded); otherwise null."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        return d["kernels"][kernel]["hbm_bytes_per_launch"] if shards == 1 else None
+        d = json.load(open(os.path.join(ROOT, PMC_PROFILE)))
+        cfg = d.get("config", {})
+        if cfg.get("workload") == workload and cfg.get("logm") == logm and cfg.get("shards", 1) == shards:
+            return d["kernels"][kernel]["hbm_bytes_per_launch"], PMC_PROFILE
+        return None, "no PMC profile for this configuration (%s was taken at workload=%s, logm=%s, shards=%s)" % (
+            PMC_PROFILE, cfg.get("workload"), cfg.get("logm"), cfg.get("shards", 1))
     except Exception:
-        return None
-
-
-def P_pick_c(n):
-    """mirror of MsmShape::pick_c (ethsnarks_amd/csrc/msm.hpp)"""
-    for c in range(17, 2, -1):
-        if n * (254 // c + 1) >= (32 << (c - 1)):
-            return c
-    return 2
+        return None, "no PMC profile committed"
 
 
 def proof_bytes(r1cs, pk, m):
@@ -249,32 +313,52 @@ def proof_bytes(r1cs, pk, m):
             + 36 * r1cs.nnz + 32 * (V + 1) + 3 * 32 * m + 7 * 2 * 32 * m + 4 * 32 * m)
 
 
-def cpu_baseline(args, pk, r1cs, wm, gpu_json, logm):
-    """The CPU oracle (restatement of r1cs_gg_ppzksnark_zok.tcc:451-550; libsnark unavailable offline)
-    on this host's cores, one proof with the same key; also the parity check of the timed GPU proof."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(args, P, R, F, pk, r1cs, wm, gpu_json, logm, device):
+    """The CPU oracle (restatement of r1cs_gg_ppzksnark_zok.tcc:451-550; libsnark unavailable offline) on this host's
+    cores: one proof of the bench's own circuit and key on all cores (also the parity check of the timed GPU proof), and a
+    one-thread figure beside it on a smaller sample (a full 2^20 proof takes about a minute on one core)."""
     sys.path[:0] = [os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")]
-    import ctypes as C
-    import numpy as np
     import oracle_lib as O
     threads = min(O.cpu_share(), 64)
     O.lib().orc_set_threads(threads)
-    parts = pk.parts()
-    h = C.c_void_p()
-    u64 = lambda a: O._p64(np.ascontiguousarray(a, dtype=np.uint64))
-    u32 = lambda a: O._p32(np.ascontiguousarray(a, dtype=np.uint32))
-    keep = {k: np.ascontiguousarray(v) for k, v in parts.items() if hasattr(v, "dtype")}
-    rc = O.lib().orc_pk_from_parts(u64(keep["alpha_g1"]), u64(keep["beta_g1"]), u64(keep["beta_g2"]), u64(keep["delta_g1"]), u64(keep["delta_g2"]),
-                                   C.c_uint32(parts["a_domain"]), C.c_uint32(len(keep["a_idx"])), u32(keep["a_idx"]), u64(keep["a_val"]),
-                                   C.c_uint32(parts["b_domain"]), C.c_uint32(len(keep["b_idx"])), u32(keep["b_idx"]), u64(keep["b_val"]),
-                                   C.c_uint32(len(keep["H"])), u64(keep["H"]), C.c_uint32(len(keep["L"])), u64(keep["L"]), C.byref(h))
-    assert rc == 0
-    opk = O.PK(h)
+    opk = O.pk_from_parts(pk.parts())
     t0 = time.perf_counter()
     js, phases = O.prove(opk, r1cs, wm)
     dt = time.perf_counter() - t0
-    base = {"value": round(1.0 / dt, 5), "unit": "proofs/s", "cores": threads, "kind": "port",
-            "sample": "1 proof of the same 2^%d circuit and key (%.1f s); CPU restatement of r1cs_gg_ppzksnark_zok.tcc:451-550, OpenMP" % (logm, dt),
+    base = {"value": round(1.0 / dt, 5), "unit": "proofs/s", "cores": threads, "kind": "port", "cpu_model": cpu_model(),
+            "constraints_per_sec": round(r1cs.nC / dt, 1),
+            "sample": "1 proof of the same 2^%d circuit and key (%.1f s); CPU restatement of r1cs_gg_ppzksnark_zok.tcc:451-550, OpenMP, %d threads" % (logm, dt, threads),
             "phases_s": [round(p, 3) for p in phases]}
+    try:                                                    # one thread, bounded sample
+        l1 = min(args.cpu_1t_logm, logm)
+        r1, w1 = R.synthetic_chain((1 << l1) - 2, 1)
+        w1m = F.fr_to_mont(w1)
+        pk1, _ = P.keygen(r1, seed=R.SEED_DEFAULT, device=device)
+        opk1 = O.pk_from_parts(pk1.parts())
+        O.lib().orc_set_threads(1)
+        t0 = time.perf_counter()
+        O.prove(opk1, r1, w1m)
+        d1 = time.perf_counter() - t0
+        O.lib().orc_set_threads(threads)
+        t0 = time.perf_counter()
+        O.prove(opk1, r1, w1m)
+        dn = time.perf_counter() - t0
+        base["one_thread"] = {"value": round(1.0 / d1, 5), "unit": "proofs/s at 2^%d" % l1, "cores": 1, "constraints_per_sec": round(r1.nC / d1, 1),
+                              "sample": "1 proof of the 2^%d chain circuit on ONE thread (%.1f s); the same proof on %d threads: %.2f s" % (l1, d1, threads, dn)}
+    except Exception as e:
+        base["one_thread"] = {"error": repr(e)[:200]}
+    finally:
+        O.lib().orc_set_threads(threads)
     return base, (js == gpu_json)
 
 

@@ -482,11 +482,13 @@ struct Curve {
             if (F::lis_zero(R)) return dbl_affine(q);
             return infinity();
         }
-        E PP = F::lsqr(Pd), PPP = F::lmul(Pd, PP), Q = F::lmul(p.X, PP);
-        XYZZ r;
+        XYZZ r;                                                        // operands die as early as possible (register pressure)
+        const E PP = F::lsqr(Pd);
+        r.ZZ = F::lmul(p.ZZ, PP);
+        const E Q = F::lmul(p.X, PP), PPP = F::lmul(Pd, PP);
+        r.ZZZ = F::lmul(p.ZZZ, PPP);
         r.X = F::lsub(F::lsub(F::lsqr(R), PPP), F::ldbl(Q));
         r.Y = F::lmul2(R, F::lsub(Q, r.X), F::lneg(p.Y), PPP);        // R (Q - X3) - Y1 PPP: one reduction
-        r.ZZ = F::lmul(p.ZZ, PP); r.ZZZ = F::lmul(p.ZZZ, PPP);
         return r;
     }
     // p + q (add-2008-s)

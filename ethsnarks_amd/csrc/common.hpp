@@ -8,8 +8,11 @@
     zk_emul::launch(true, dim3(grid), dim3(block), [&] { kern(__VA_ARGS__); })
 #else
 #include <hip/hip_runtime.h>
+// every kernel launch goes through this macro: it counts launches, and between zk_profile_begin() / zk_profile_end()
+// (a measurement aid of bench.py, off on the proving path) brackets each launch with a HIP event pair on its stream
+namespace zk { void launch_pre(const char *name, hipStream_t st); void launch_post(hipStream_t st); }
 #define ZK_LAUNCH(kern, grid, block, stream, ...) \
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, stream, __VA_ARGS__)
+    do { zk::launch_pre(#kern, stream); hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, stream, __VA_ARGS__); zk::launch_post(stream); } while (0)
 #define ZK_LAUNCH_SYNC ZK_LAUNCH
 #endif
 #define ZK_HD __host__ __device__ __forceinline__

@@ -5,7 +5,7 @@
 namespace zk {
 
 template <class C>
-__global__ void __launch_bounds__(64, C::WAVES_PER_SIMD)
+__global__ void __launch_bounds__(64, C::WAVES_PER_SIMD / 2)
 k_batch_mul_base(typename C::Affine base, const fe *__restrict__ scalars, uint32_t n, typename C::Affine *__restrict__ out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;

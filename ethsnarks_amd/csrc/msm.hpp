@@ -156,6 +156,7 @@ struct MsmWork {
     uint32_t *heavy_list = nullptr, *heavy_count = nullptr;
     typename C::XYZZ *segsum = nullptr, *bucket = nullptr, *partial_a = nullptr, *partial_b = nullptr;
     typename C::XYZZ *host_result = nullptr;    // pinned, 1 entry
+    typename C::XYZZ *dev_result = nullptr;     // optional: a device copy of the result as well (sharded provers exchange it with RCCL)
     hipEvent_t ev_acc0 = nullptr, ev_acc1 = nullptr;   // bracket k_msm_accumulate (the dominant kernel) on its stream
     float accumulate_ms() const { float ms = 0; if (ev_acc0 && ev_acc1) hipEventElapsedTime(&ms, ev_acc0, ev_acc1); return ms; }
 

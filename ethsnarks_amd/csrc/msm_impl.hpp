@@ -239,9 +239,11 @@ k_msm_accumulate(const typename C::Affine *__restrict__ table, const uint32_t *_
     if (ql == 0) piece[c + b] = acc;
 }
 
-// thread / quad per bucket: sum its chunk pieces (serial; buckets over MSM_HEAVY pieces are queued)
+// thread / quad per bucket: sum its chunk pieces (serial; buckets over MSM_HEAVY pieces are queued).
+// The bucket-reduction tails are chains of dependent group operations run by few waves: their launch bounds ask for
+// registers (no scratch), not for occupancy.
 template <class C, int Q>
-__global__ void __launch_bounds__(64, C::WAVES_PER_SIMD)
+__global__ void __launch_bounds__(64, C::WAVES_PER_SIMD / 2)
 k_msm_bucket_finalize(const typename C::XYZZ *__restrict__ piece, const uint32_t *__restrict__ off,
                       uint32_t nb, ChunkRule rule, typename C::XYZZ *__restrict__ bucket,
                       uint32_t *__restrict__ heavy_list, uint32_t *__restrict__ heavy_count) {
@@ -282,7 +284,7 @@ k_msm_heavy(const typename C::XYZZ *__restrict__ piece, const uint32_t *__restri
 
 // thread / quad per group of K consecutive buckets:  sum_j (g*K + j + 1) * B_{g*K+j}
 template <class C, int Q>
-__global__ void __launch_bounds__(64, C::WAVES_PER_SIMD)
+__global__ void __launch_bounds__(64, C::WAVES_PER_SIMD / 2)
 k_msm_group_reduce(const typename C::XYZZ *__restrict__ bucket, uint32_t nb, uint32_t K,
                    typename C::XYZZ *__restrict__ partial) {
     const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x, g = gt / Q, ql = gt % Q;

@@ -4,12 +4,14 @@
 //   pk_nozk stream operators       ...tcc:108-143
 //   proof_to_json                  src/export.cpp:20-121
 // around the kernels of ntt.hpp / msm.hpp.  No CPU compute path exists in this library.
+#include <algorithm>
 #include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
 #include <chrono>
 #include <string.h>
+#include <stddef.h>
 #include <stdlib.h>
 
 #include "common.hpp"
@@ -21,6 +23,78 @@
 
 namespace zk { thread_local char g_last_error[256] = ""; }
 using namespace zk;
+
+// ---- launch accounting (common.hpp: ZK_LAUNCH)
+#ifndef ZK_EMUL
+namespace {
+std::atomic<uint64_t> g_launches{0};
+std::atomic<bool> g_prof_on{false};
+std::mutex g_prof_mu;
+struct ProfRec { const char *name; hipEvent_t e0, e1; };
+std::vector<ProfRec> g_prof;
+thread_local hipEvent_t t_pending = nullptr;
+}  // namespace
+void zk::launch_pre(const char *name, hipStream_t st) {
+    g_launches.fetch_add(1, std::memory_order_relaxed);
+    if (!g_prof_on.load(std::memory_order_relaxed)) return;
+    ProfRec r{name, nullptr, nullptr};
+    if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
+    (void)hipEventRecord(r.e0, st);
+    t_pending = r.e1;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof.push_back(r);
+}
+void zk::launch_post(hipStream_t st) {
+    if (t_pending) { (void)hipEventRecord(t_pending, st); t_pending = nullptr; }
+}
+extern "C" uint64_t zk_launch_count(void) { return g_launches.load(); }
+extern "C" int zk_profile_begin(void) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto &r : g_prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+    g_prof.clear();
+    g_prof_on = true;
+    return ZK_OK;
+}
+extern "C" int zk_profile_end(float *kernel_ms_sum, uint32_t *launches, char *buf, size_t cap) {
+    g_prof_on = false;
+    if (hipDeviceSynchronize() != hipSuccess) return fail_msg(ZK_ERR_HIP, "hipDeviceSynchronize failed");
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    float sum = 0;
+    std::vector<std::pair<std::string, std::pair<float, uint32_t>>> by;      // name -> (ms, calls)
+    for (auto &r : g_prof) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) ms = 0;
+        sum += ms;
+        bool found = false;
+        for (auto &b : by) if (b.first == r.name) { b.second.first += ms; b.second.second++; found = true; break; }
+        if (!found) by.push_back({r.name, {ms, 1u}});
+        hipEventDestroy(r.e0); hipEventDestroy(r.e1);
+    }
+    if (kernel_ms_sum) *kernel_ms_sum = sum;
+    if (launches) *launches = (uint32_t)g_prof.size();
+    g_prof.clear();
+    if (buf && cap) {                                     // "name calls ms" lines, longest first
+        std::sort(by.begin(), by.end(), [](const auto &a, const auto &b) { return a.second.first > b.second.first; });
+        std::string s;
+        for (auto &b : by) { char line[256]; snprintf(line, sizeof(line), "%s %u %.4f\n", b.first.c_str(), b.second.second, b.second.first); s += line; }
+        snprintf(buf, cap, "%s", s.c_str());
+    }
+    return ZK_OK;
+}
+extern "C" int zk_device_info(int device, uint32_t *compute_units, uint32_t *clock_mhz, char *name, size_t name_cap) {
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, device) != hipSuccess) return fail_msg(ZK_ERR_NODEVICE, "hipGetDeviceProperties failed: no usable HIP device");
+    if (compute_units) *compute_units = (uint32_t)p.multiProcessorCount;
+    if (clock_mhz) *clock_mhz = (uint32_t)(p.clockRate / 1000);
+    if (name && name_cap) snprintf(name, name_cap, "%s", p.name);
+    return ZK_OK;
+}
+#else
+extern "C" uint64_t zk_launch_count(void) { return 0; }
+extern "C" int zk_profile_begin(void) { return ZK_OK; }
+extern "C" int zk_profile_end(float *s, uint32_t *n, char *buf, size_t cap) { if (s) *s = 0; if (n) *n = 0; if (buf && cap) buf[0] = 0; return ZK_OK; }
+extern "C" int zk_device_info(int, uint32_t *cu, uint32_t *mhz, char *name, size_t cap) { if (cu) *cu = 1; if (mhz) *mhz = 0; if (name && cap) snprintf(name, cap, "emulation"); return ZK_OK; }
+#endif
 
 static int fail(int code, const char *msg) { return fail_msg(code, msg); }
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -445,6 +519,7 @@ struct zk_ctx {
     uint32_t *dA_idx = nullptr, *dB_idx = nullptr;
     DevCsr cA, cB, cC;
     fe *d_w = nullptr, *d_a = nullptr, *d_b = nullptr, *d_c = nullptr, *d_t = nullptr;
+    uint8_t *d_partials = nullptr;             // 640 bytes: the four partial sums in zk_partials layout, device copy
     fe *h_w = nullptr;                         // pinned staging for the witness
     fe *h_tail = nullptr;                      // pinned: h[m-1] for the degree check
     NttTables tab;
@@ -454,7 +529,7 @@ struct zk_ctx {
                ev_l0 = nullptr, ev_l1 = nullptr, ev_h1 = nullptr, ev_h0 = nullptr;
     ~zk_ctx() {
         hipSetDevice(device);
-        void *dev[] = {d_w, d_a, d_t};                       // d_b, d_c live inside d_a's allocation
+        void *dev[] = {d_w, d_a, d_t, d_partials};           // d_b, d_c live inside d_a's allocation
         for (void *p : dev) if (p) hipFree(p);
         if (h_w) hipHostFree(h_w);
         if (h_tail) hipHostFree(h_tail);
@@ -539,6 +614,9 @@ static int ctx_build(zk_ctx *c, const zk_pk *pk, const zk_csr *A, const zk_csr *
     ZK_HIP(hipMalloc(&c->d_w, 32 * (size_t)(V + 1)));
     ZK_HIP(hipMalloc(&c->d_a, 3 * 32 * (size_t)m)); c->d_b = c->d_a + m; c->d_c = c->d_a + 2 * (size_t)m;   // A | B | C: one batched NTT launch per pass
     ZK_HIP(hipMalloc(&c->d_t, 3 * 32 * (size_t)m));
+    ZK_HIP(hipMalloc(&c->d_partials, sizeof(zk_partials)));
+    c->mA.dev_result = (G1::XYZZ *)(c->d_partials + offsetof(zk_partials, At)); c->mB.dev_result = (G2::XYZZ *)(c->d_partials + offsetof(zk_partials, Bt));
+    c->mH.dev_result = (G1::XYZZ *)(c->d_partials + offsetof(zk_partials, Ht)); c->mL.dev_result = (G1::XYZZ *)(c->d_partials + offsetof(zk_partials, Lt));
     ZK_HIP(hipHostMalloc(&c->h_w, 32 * (size_t)(V + 1), hipHostMallocDefault));
     ZK_HIP(hipHostMalloc(&c->h_tail, 32, hipHostMallocDefault));
     // s_main carries the critical chain (H polynomial -> H-query): highest priority; the A-, B-, L-query
@@ -605,10 +683,13 @@ static int enqueue_compute_h(zk_ctx *c) {
     return ZK_OK;
 }
 
-static int upload_witness(zk_ctx *c, const uint64_t *witness, int canonical) {
-    memcpy(c->h_w, witness, 32 * (size_t)(c->V + 1));
+// witness: a host buffer (staged through pinned memory, the reference's pb.values), or -- resident != 0 -- a buffer that
+// already lives in this device's memory (the caller keeps it untouched until the proof is collected)
+static int upload_witness(zk_ctx *c, const uint64_t *witness, int canonical, int resident = 0) {
+    if (!resident) memcpy(c->h_w, witness, 32 * (size_t)(c->V + 1));
     ZK_HIP(hipEventRecord(c->ev_start, c->s_main));
-    ZK_HIP(hipMemcpyAsync(c->d_w, c->h_w, 32 * (size_t)(c->V + 1), hipMemcpyHostToDevice, c->s_main));
+    if (resident) ZK_HIP(hipMemcpyAsync(c->d_w, witness, 32 * (size_t)(c->V + 1), hipMemcpyDeviceToDevice, c->s_main));
+    else ZK_HIP(hipMemcpyAsync(c->d_w, c->h_w, 32 * (size_t)(c->V + 1), hipMemcpyHostToDevice, c->s_main));
     if (canonical) ZK_LAUNCH(k_to_mont, zk_div_up(c->V + 1, 256), 256, c->s_main, c->d_w, c->V + 1);
     ZK_HIP(hipEventRecord(c->ev_w, c->s_main));
     return ZK_OK;
@@ -617,12 +698,12 @@ static int upload_witness(zk_ctx *c, const uint64_t *witness, int canonical) {
 static void store_xyzz(uint64_t *dst, const G1::XYZZ &p) { memcpy(dst, &p, sizeof(p)); }
 static void store_xyzz(uint64_t *dst, const G2::XYZZ &p) { memcpy(dst, &p, sizeof(p)); }
 
-static int prove_enqueue(zk_ctx *c, const uint64_t *witness, int canonical);
-static int prove_submit_impl(zk_ctx *c, const uint64_t *witness, int canonical) {
+static int prove_enqueue(zk_ctx *c, const uint64_t *witness, int canonical, int resident);
+static int prove_submit_impl(zk_ctx *c, const uint64_t *witness, int canonical, int resident = 0) {
     if (!c || !witness) return fail(ZK_ERR_ARG, "null argument");
     if (c->in_flight) return fail(ZK_ERR_ARG, "a proof is already in flight on this context (collect it first)");
     ZK_TRY(use_device(c->device));
-    const int rc = prove_enqueue(c, witness, canonical);
+    const int rc = prove_enqueue(c, witness, canonical, resident);
     if (rc != ZK_OK) {      // part of the proof may be queued: drain it so that the next submit cannot overwrite buffers still in use
         hipStreamSynchronize(c->s_main); hipStreamSynchronize(c->s_a); hipStreamSynchronize(c->s_b); hipStreamSynchronize(c->s_l);
         return rc;
@@ -630,8 +711,8 @@ static int prove_submit_impl(zk_ctx *c, const uint64_t *witness, int canonical) 
     c->in_flight = true;
     return ZK_OK;
 }
-static int prove_enqueue(zk_ctx *c, const uint64_t *witness, int canonical) {
-    ZK_TRY(upload_witness(c, witness, canonical));
+static int prove_enqueue(zk_ctx *c, const uint64_t *witness, int canonical, int resident) {
+    ZK_TRY(upload_witness(c, witness, canonical, resident));
     // One in-order stream carries every machine-filling kernel (sorts, accumulations, the H pipeline) so that
     // none of them is stretched by contention; the low-parallelism bucket reductions ("tails") of the B-, A-
     // and L-query run on side streams beside the next accumulation.  Longest tail (G2) first; the H-query is
@@ -659,8 +740,8 @@ static int prove_enqueue(zk_ctx *c, const uint64_t *witness, int canonical) {
     return ZK_OK;
 }
 
-static int prove_collect_impl(zk_ctx *c, zk_partials *out, zk_timings *tm) {
-    if (!c || !out) return fail(ZK_ERR_ARG, "null argument");
+static int prove_collect_impl(zk_ctx *c, zk_partials *out, zk_timings *tm) {     // out == nullptr: the caller takes the device copy
+    if (!c) return fail(ZK_ERR_ARG, "null argument");
     if (!c->in_flight) return fail(ZK_ERR_ARG, "no proof in flight on this context");
     ZK_TRY(use_device(c->device));
     c->in_flight = false;
@@ -668,8 +749,10 @@ static int prove_collect_impl(zk_ctx *c, zk_partials *out, zk_timings *tm) {
     ZK_HIP(hipStreamSynchronize(c->s_l)); ZK_HIP(hipStreamSynchronize(c->s_main));
     if (!Fr::is_zero(*c->h_tail)) return fail(ZK_ERR_DEGREE, "h[m-1] != 0: the witness does not satisfy the constraint system");
     double t0 = now_ms();
-    store_xyzz(out->At, c->mA.finish()); store_xyzz(out->Bt, c->mB.finish());
-    store_xyzz(out->Ht, c->mH.finish()); store_xyzz(out->Lt, c->mL.finish());
+    if (out) {
+        store_xyzz(out->At, c->mA.finish()); store_xyzz(out->Bt, c->mB.finish());
+        store_xyzz(out->Ht, c->mH.finish()); store_xyzz(out->Lt, c->mL.finish());
+    }
     if (tm) {
         memset(tm, 0, sizeof(*tm));
         hipEventElapsedTime(&tm->h2d_witness, c->ev_start, c->ev_w);
@@ -698,7 +781,20 @@ static int prove_partial_impl(zk_ctx *c, const uint64_t *witness, int canonical,
 }
 // asynchronous form: enqueue a proof and return; collect later (lets two contexts keep the GPU full)
 extern "C" int zk_prove_submit(zk_ctx *ctx, const uint64_t *witness, int canonical) { return prove_submit_impl(ctx, witness, canonical); }
-extern "C" int zk_prove_collect(zk_ctx *ctx, zk_partials *out, zk_timings *t) { return prove_collect_impl(ctx, out, t); }
+extern "C" int zk_prove_submit_resident(zk_ctx *ctx, const void *d_witness, int canonical) { return prove_submit_impl(ctx, (const uint64_t *)d_witness, canonical, 1); }
+// what the context chose: {window bits, windows, buckets} of the A-, B-, H-, L-query MSMs, then whether the witness sort is shared
+extern "C" int zk_ctx_info(const zk_ctx *c, uint32_t info[16]) {
+    if (!c || !info) return fail(ZK_ERR_ARG, "null argument");
+    const MsmShape *sh[4] = {&c->mA.sh, &c->mB.sh, &c->mH.sh, &c->mL.sh};
+    for (int i = 0; i < 4; i++) { info[3 * i] = sh[i]->c; info[3 * i + 1] = sh[i]->W; info[3 * i + 2] = sh[i]->nb; }
+    info[12] = c->tables->share_A; info[13] = c->tables->share_B; info[14] = c->tables->share_L; info[15] = c->m;
+    return ZK_OK;
+}
+extern "C" int zk_prove_collect(zk_ctx *ctx, zk_partials *out, zk_timings *t) { if (!out) return fail(ZK_ERR_ARG, "null argument"); return prove_collect_impl(ctx, out, t); }
+// device-side exchange of sharded provers: the partial sums stay in a 640-byte device buffer of the context (zk_partials layout,
+// loose Montgomery values), ready for an RCCL all-gather; zk_prove_combine_device takes the gathered device buffer
+extern "C" const void *zk_ctx_partials_device(const zk_ctx *ctx) { return ctx ? ctx->d_partials : nullptr; }
+extern "C" int zk_prove_collect_device(zk_ctx *ctx, zk_timings *t) { return prove_collect_impl(ctx, nullptr, t); }
 
 template <class F> static void canon4(uint64_t dst[4], const fe &mont) { fe c = F::from_mont(mont); memcpy(dst, c.l, 32); }
 static void put_g1(const G1::XYZZ &p, uint64_t x[4], uint64_t y[4], uint32_t *inf) {
@@ -730,6 +826,19 @@ extern "C" int zk_prove_combine(const zk_ctx *c, const zk_partials *parts, uint3
     put_g2(gB, out->b_x_c0, out->b_x_c1, out->b_y_c0, out->b_y_c1, &out->b_inf);
     put_g1(gC, out->c_x, out->c_y, &out->c_inf);
     return ZK_OK;
+}
+
+extern "C" int zk_prove_combine_device(const zk_ctx *c, const void *d_parts, uint32_t count, zk_proof *out) {
+    if (!c || !d_parts || !count || !out) return fail(ZK_ERR_ARG, "null argument");
+    ZK_TRY(use_device(c->device));
+    std::vector<zk_partials> parts(count);
+    ZK_HIP(hipMemcpy(parts.data(), d_parts, sizeof(zk_partials) * (size_t)count, hipMemcpyDeviceToHost));
+    for (auto &p : parts) {                                  // device values are loose ([0, 2p)): normalise once
+        G1::XYZZ a, h, l; G2::XYZZ b;
+        memcpy(&a, p.At, sizeof(a)); memcpy(&b, p.Bt, sizeof(b)); memcpy(&h, p.Ht, sizeof(h)); memcpy(&l, p.Lt, sizeof(l));
+        store_xyzz(p.At, G1::canon(a)); store_xyzz(p.Bt, G2::canon(b)); store_xyzz(p.Ht, G1::canon(h)); store_xyzz(p.Lt, G1::canon(l));
+    }
+    return zk_prove_combine(c, parts.data(), count, out);
 }
 
 extern "C" int zk_prove_partial(zk_ctx *ctx, const uint64_t *witness, int canonical, zk_partials *out) {

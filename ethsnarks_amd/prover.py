@@ -60,6 +60,7 @@ EXPORTS = [
     "zk_keygen", "zk_vk_to_json", "zk_vk_from_json", "zk_proof_from_json", "zk_vk_free",
     "zk_domain_size", "zk_ctx_create", "zk_ctx_destroy",
     "zk_prove", "zk_prove_timed", "zk_prove_partial", "zk_prove_partial_timed", "zk_prove_combine", "zk_prove_submit", "zk_prove_collect", "zk_proof_to_json",
+    "zk_prove_submit_resident", "zk_ctx_info", "zk_ctx_partials_device", "zk_prove_collect_device", "zk_prove_combine_device", "zk_launch_count", "zk_profile_begin", "zk_profile_end", "zk_device_info",
     "zk_verify",
     "zk_ntt", "zk_witness_map", "zk_msm_g1", "zk_msm_g2", "zk_field_mul",
 ]
@@ -82,6 +83,8 @@ def load_library(path=None):
         getattr(L, n).restype = C.c_char_p
     L.zk_pk_part.restype = C.c_void_p
     L.zk_domain_size.restype = C.c_uint32
+    L.zk_launch_count.restype = C.c_uint64
+    L.zk_ctx_partials_device.restype = C.c_void_p
     _lib, _lib_path_loaded = L, path
     return L
 
@@ -338,11 +341,41 @@ class ProverContext:
         w = self._w(witness)
         _check(_lib.zk_prove_submit(self._h, _p64(w), int(canonical)))
 
+    def submit_resident(self, device_ptr, canonical=False):
+        """zk_prove_submit_resident: the witness already lives in this device's memory (device_ptr = integer address of
+        (V + 1) x 32 bytes); the caller keeps that buffer untouched until collect()"""
+        _check(_lib.zk_prove_submit_resident(self._h, C.c_void_p(device_ptr), int(canonical)))
+
+    def info(self):
+        """window bits / windows / buckets per query, shared-sort flags, domain size (zk_ctx_info)"""
+        a = (C.c_uint32 * 16)()
+        _check(_lib.zk_ctx_info(self._h, a))
+        v = list(a)
+        d = {q: {"c": v[3 * i], "W": v[3 * i + 1], "buckets": v[3 * i + 2]} for i, q in enumerate("ABHL")}
+        d.update(share_A=bool(v[12]), share_B=bool(v[13]), share_L=bool(v[14]), m=v[15])
+        return d
+
     def collect(self):
         """wait for the submitted proof: (partials[80 u64], timings dict)"""
         part, t = ZkPartials(), ZkTimings()
         _check(_lib.zk_prove_collect(self._h, C.byref(part), C.byref(t)))
         return np.frombuffer(bytes(part), dtype=np.uint64).copy(), t.as_dict()
+
+    def partials_device_ptr(self):
+        """address of the context's 640-byte device copy of the partial sums (valid after collect_device)"""
+        return int(_lib.zk_ctx_partials_device(self._h))
+
+    def collect_device(self):
+        """wait for the submitted proof, leave the partial sums on the device: timings dict"""
+        t = ZkTimings()
+        _check(_lib.zk_prove_collect_device(self._h, C.byref(t)))
+        return t.as_dict()
+
+    def prove_combine_device(self, device_ptr, count):
+        """fold `count` gathered 640-byte records that live in device memory (zk_prove_combine_device)"""
+        proof = ZkProof()
+        _check(_lib.zk_prove_combine_device(self._h, C.c_void_p(device_ptr), C.c_uint32(count), C.byref(proof)))
+        return proof
 
     def prove_combine(self, partials):
         arr = _c64(partials).reshape(-1, 80)
@@ -415,6 +448,34 @@ def stub_test_proof_verify(r1cs, witness, **kw):
         return stub_verify(vk.to_json(), prove(ctx, witness))
     finally:
         ctx.close()
+
+
+# ---- measurement aids
+def launch_count():
+    return int(load_library(_lib_path_loaded).zk_launch_count())
+
+
+def profile_begin():
+    _check(load_library(_lib_path_loaded).zk_profile_begin())
+
+
+def profile_end():
+    """(sum of kernel durations in ms, launches, {kernel: (calls, ms)})"""
+    s, n = C.c_float(0), C.c_uint32(0)
+    buf = C.create_string_buffer(1 << 16)
+    _check(load_library(_lib_path_loaded).zk_profile_end(C.byref(s), C.byref(n), buf, C.c_size_t(len(buf))))
+    per = {}
+    for line in buf.value.decode().splitlines():
+        name, calls, ms = line.rsplit(" ", 2)
+        per[name] = (int(calls), float(ms))
+    return float(s.value), int(n.value), per
+
+
+def device_info(device=0):
+    cu, mhz = C.c_uint32(0), C.c_uint32(0)
+    name = C.create_string_buffer(256)
+    _check(load_library(_lib_path_loaded).zk_device_info(device, C.byref(cu), C.byref(mhz), name, C.c_size_t(256)))
+    return {"compute_units": int(cu.value), "clock_mhz": int(mhz.value), "name": name.value.decode()}
 
 
 # ---- kernel-level entry points

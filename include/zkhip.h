@@ -163,6 +163,18 @@ int zk_prove_combine(const zk_ctx *ctx, const zk_partials *parts, uint32_t count
  * per concurrent prover in the reference too, hpp:279-291). */
 int zk_prove_submit(zk_ctx *ctx, const uint64_t *witness, int canonical);
 int zk_prove_collect(zk_ctx *ctx, zk_partials *out, zk_timings *t);
+/* sharded provers, exchange on device buffers: after zk_prove_collect_device the four partial sums sit in a 640-byte device
+ * buffer owned by the context (zk_ctx_partials_device; zk_partials layout) -- the send buffer of an RCCL all-gather;
+ * zk_prove_combine_device folds `count` gathered 640-byte records (device pointer) in rank order like zk_prove_combine */
+const void *zk_ctx_partials_device(const zk_ctx *ctx);
+int zk_prove_collect_device(zk_ctx *ctx, zk_timings *t);
+int zk_prove_combine_device(const zk_ctx *ctx, const void *d_parts, uint32_t count, zk_proof *out);
+/* zk_prove_submit for a witness that is already resident in the context's device memory (d_witness = device
+ * pointer to (V + 1) x 32 bytes, e.g. written by a GPU witness generator); it must stay untouched until collected */
+int zk_prove_submit_resident(zk_ctx *ctx, const void *d_witness, int canonical);
+/* info[3q .. 3q+2] = {window bits c, windows W, buckets 2^(c-1)} of query q = A, B, H, L; info[12..14] = the A-, B-, L-query
+ * ride the shared witness sort; info[15] = domain size m */
+int zk_ctx_info(const zk_ctx *ctx, uint32_t info[16]);
 
 /* inputs: nIn Fr elements = witness[1..nIn] (Montgomery unless canonical); returns the JSON length
  * (excluding NUL) through *len; ZK_ERR_BUFFER if cap is too small (len still set) */
@@ -174,6 +186,14 @@ int zk_proof_to_json(const zk_proof *proof, const uint64_t *inputs, uint32_t nIn
 int zk_verify(const char *vk_json, const char *proof_json, int *accepted);
 /* same symbol and signature as the reference's libethsnarks_verify (src/verify_dll.cpp:3-10) */
 bool ethsnarks_verify(const char *vk_json, const char *proof_json);
+
+/* ---- measurement aids (bench.py): kernel launches issued by this library so far; between zk_profile_begin() and
+ * zk_profile_end() every launch is bracketed by a HIP event pair on its own stream -- the sum of the kernel durations
+ * (overlapping kernels counted each), their number, and "name calls ms" lines per kernel come back */
+uint64_t zk_launch_count(void);
+int zk_profile_begin(void);
+int zk_profile_end(float *kernel_ms_sum, uint32_t *launches, char *buf, size_t cap);
+int zk_device_info(int device, uint32_t *compute_units, uint32_t *clock_mhz, char *name, size_t name_cap);
 
 /* ---- kernel-level entry points (parity tests / micro-benchmarks); host buffers in and out */
 int zk_ntt(uint64_t *data, uint32_t logm, int inverse, int coset, int device);
