@@ -14,7 +14,11 @@ res = {}
 for k in sorted(set(fetch) | set(write)):
     f, w = fetch.get(k, 0.0) * 1024, write.get(k, 0.0) * 1024
     res[k] = {"fetch_bytes_raw": f, "fetch_bytes_corrected_x2": 2 * f, "write_bytes": w, "hbm_bytes_per_launch": 2 * f + w}
-json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 2 --warmup 1 --inflight 1, 2^20",
+json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 2 --warmup 1 --inflight 1 --no-extras --no-cpu-baseline, 2^20",
+           "config": {"workload": "chain", "logm": 20, "shards": 1},
+           "note": "hbm_bytes_per_launch = 2 x FETCH_SIZE + WRITE_SIZE.  The x2 FETCH correction is documented for wide coalesced streams "
+                   "(MI355X_MICROARCH.md, HBM); the accumulation kernels read 64-byte (G1) / 128-byte (G2) gathered points, for which it is "
+                   "uncalibrated: read their figures as an UPPER bound (between 1x and 2x the raw counter).",
            "kernels": res}, open(out, "w"), indent=1)
 for k, v in sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"])[:12]:
     print("%-36s %10.1f MB" % (k, v["hbm_bytes_per_launch"] / 1e6))
