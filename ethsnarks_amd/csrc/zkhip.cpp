@@ -1113,6 +1113,17 @@ extern "C" int zk_msm_g2(const uint64_t *bases, const uint64_t *scalars, uint32_
     return msm_host<G2>(bases, scalars, n, c, device, out);
 }
 
+// host-only: Fr elements between the canonical and the Montgomery (libff::Fp_model) representation, in place
+extern "C" int zk_fr_convert(uint64_t *io, uint32_t n, int to_montgomery) {
+    if (n && !io) return fail(ZK_ERR_ARG, "null argument");
+    for (uint32_t i = 0; i < n; i++) {
+        fe v; memcpy(v.l, io + 4 * (size_t)i, 32);
+        v = to_montgomery ? Fr::to_mont(v) : Fr::from_mont(v);
+        memcpy(io + 4 * (size_t)i, v.l, 32);
+    }
+    return ZK_OK;
+}
+
 extern "C" int zk_field_mul(const uint64_t *a, const uint64_t *b, uint64_t *out, uint32_t n, int field, int device) {
     if (!a || !b || !out) return fail(ZK_ERR_ARG, "null argument");
     ZK_TRY(use_device(device));

@@ -62,7 +62,7 @@ EXPORTS = [
     "zk_prove", "zk_prove_timed", "zk_prove_partial", "zk_prove_partial_timed", "zk_prove_combine", "zk_prove_submit", "zk_prove_collect", "zk_proof_to_json",
     "zk_prove_submit_resident", "zk_ctx_info", "zk_ctx_partials_device", "zk_prove_collect_device", "zk_prove_combine_device", "zk_launch_count", "zk_profile_begin", "zk_profile_end", "zk_device_info",
     "zk_verify",
-    "zk_ntt", "zk_witness_map", "zk_msm_g1", "zk_msm_g2", "zk_field_mul",
+    "zk_ntt", "zk_witness_map", "zk_msm_g1", "zk_msm_g2", "zk_field_mul", "zk_fr_convert",
 ]
 
 _lib = None

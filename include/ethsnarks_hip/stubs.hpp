@@ -39,32 +39,92 @@
 #include <vector>
 #include <unistd.h>
 
+#include <algorithm>
+#include <ostream>
+#include <type_traits>
+#include <utility>
+
+// ---- libsnark::Config, source-compatible with src/prover_config.hpp:8-85 (same members and defaults, the printer, and
+// get_cpu_ranges).  The guard is the reference's own: whichever of the two headers comes first defines the struct, the
+// other is skipped.  The CPU-cache knobs are accepted and ignored; multi_exp_c is honoured.
+#ifndef ETHSNARKS_PROVER_CONFIG_HPP_
+#define ETHSNARKS_PROVER_CONFIG_HPP_
+namespace libsnark {
+struct Config {
+    Config() : num_threads(1), smt(false), fft("recursive"), swapAB(true), multi_exp_c(0), multi_exp_prefetch_locality(0),
+               prefetch_stride(128), multi_exp_look_ahead(1) {}
+    unsigned int num_threads;
+    bool smt;
+    std::string fft;
+    std::vector<unsigned int> radixes;
+    bool swapAB;
+    unsigned int multi_exp_c;
+    unsigned int multi_exp_prefetch_locality;
+    unsigned int prefetch_stride;
+    unsigned int multi_exp_look_ahead;
+};
+inline std::ostream &operator<<(std::ostream &os, const Config &c) {       // the reference's line, field for field
+    os << "num_threads: " << c.num_threads << ", smt: " << c.smt << ", fft: " << c.fft << ", radixes: [";
+    for (size_t i = 0; i < c.radixes.size(); i++) os << (i ? "," : "") << c.radixes[i];
+    return os << "], exp_c: " << c.multi_exp_c << ", pre_stride: " << c.prefetch_stride << ", exp_preloc: "
+              << c.multi_exp_prefetch_locality << ", exp_lookahead: " << c.multi_exp_look_ahead;
+}
+// [startIdx, length) cut into at most num_threads near-equal ranges (0 = one range here: no OpenMP on this side)
+inline std::vector<std::pair<unsigned int, unsigned int>> get_cpu_ranges(unsigned int startIdx, unsigned int length, unsigned int num_threads = 0) {
+    std::vector<std::pair<unsigned int, unsigned int>> ranges;
+    if (startIdx >= length) return ranges;
+    const unsigned int dist = length - startIdx, n = std::min<unsigned int>(num_threads ? num_threads : 1u, dist);
+    const unsigned int chunk = dist / n, rem = dist % n;
+    for (unsigned int i = 0; i + 1 < n; i++) { const unsigned int end = startIdx + chunk + (i < rem ? 1 : 0); ranges.emplace_back(startIdx, end); startIdx = end; }
+    ranges.emplace_back(startIdx, length);
+    return ranges;
+}
+}  // namespace libsnark
+#endif
+
+// ---- front-end types.  With libsnark on the include path its protoboard / gadget classes are used and the aliases of
+// src/ethsnarks.hpp:31-41 are restated here -- NOT taken from that header, whose ProvingKeyT / ProverContextT (:43,48) name
+// libsnark's CPU prover types and would collide with the ones below.  Its include guard is claimed, so gadget headers that
+// say #include "ethsnarks.hpp" get these aliases instead.  Without libsnark, ethsnarks_hip/circuit.hpp supplies the names.
 #if __has_include(<libsnark/gadgetlib1/protoboard.hpp>)
+#ifdef ETHSNARKS_HPP_
+#error "include ethsnarks_hip/stubs.hpp INSTEAD of the reference's ethsnarks.hpp / stubs.hpp (their ProvingKeyT / ProverContextT are libsnark's CPU prover types)"
+#endif
+#define ETHSNARKS_HPP_
 #include <libsnark/gadgetlib1/protoboard.hpp>
-#include "ethsnarks.hpp"          // FieldT, ProtoboardT, ppT (src/ethsnarks.hpp:31-48)
+#include <libsnark/gadgetlib1/gadget.hpp>
+#if defined(CURVE_MCL_BN128)
+#include <libff/algebra/curves/mcl_bn128/mcl_bn128_pp.hpp>
+#else
+#include <libff/algebra/curves/alt_bn128/alt_bn128_pp.hpp>
+#endif
+namespace ethsnarks {
+#if defined(CURVE_MCL_BN128)
+typedef libff::mcl_bn128_pp ppT;            // its Fr wrapper's memory image is defined in the absent libff fork: values cross the
+#define ETHSNARKS_HIP_FR_VIA_BIGINT 1       // boundary through as_bigint() (canonical), not by reinterpreting the object
+#else
+typedef libff::alt_bn128_pp ppT;            // Fr = libff::Fp_model<4>: 4 x u64 Montgomery limbs, passed by pointer
+#endif
+typedef libff::Fr<ppT> FieldT;
+typedef libsnark::r1cs_constraint<FieldT> ConstraintT;
+typedef libsnark::protoboard<FieldT> ProtoboardT;
+typedef libsnark::pb_variable<FieldT> VariableT;
+typedef libsnark::pb_variable_array<FieldT> VariableArrayT;
+typedef libsnark::pb_linear_combination<FieldT> LinearCombinationT;
+typedef libsnark::pb_linear_combination_array<FieldT> LinearCombinationArrayT;
+typedef libsnark::linear_term<FieldT> LinearTermT;
+typedef libsnark::gadget<FieldT> GadgetT;
+}  // namespace ethsnarks
 #define ETHSNARKS_HIP_HAVE_LIBSNARK 1
 #else
 #include "circuit.hpp"            // stand-alone front end with the same surface (FieldT, ProtoboardT, VariableT, ...)
 #define ETHSNARKS_HIP_HAVE_LIBSNARK 0
 #endif
 
-namespace libsnark {
-// source-compatible with src/prover_config.hpp:8-35; the CPU-cache knobs are accepted and ignored
-struct Config {
-    unsigned int num_threads = 1;
-    bool smt = false;
-    std::string fft = "recursive";
-    std::vector<unsigned int> radixes;
-    bool swapAB = true;
-    unsigned int multi_exp_c = 0;
-    unsigned int multi_exp_prefetch_locality = 0;
-    unsigned int prefetch_stride = 128;
-    unsigned int multi_exp_look_ahead = 1;
-    unsigned int device = 0;               // added: HIP device ordinal
-};
-}  // namespace libsnark
-
 namespace ethsnarks {
+
+// HIP device the contexts of this process are created on (the reference has no such notion; default 0)
+inline unsigned int &hip_device() { static unsigned int d = 0; return d; }
 
 struct zk_error : std::runtime_error {
     int code;
@@ -91,7 +151,11 @@ private:
 
 inline ProvingKeyT load_proving_key(const char *pk_file) {
     zk_pk *h = nullptr;
+#if defined(CURVE_MCL_BN128)
+    zk_check(zk_pk_load_raw(pk_file, ZK_CODEC_MCL_BN128, &h));     // inferred element layout, parity unpinned (include/zkhip.h)
+#else
     zk_check(zk_pk_load_raw(pk_file, ZK_CODEC_ALT_BN128, &h));     // the reference asserts on a missing file (utils.hpp:180)
+#endif
     return ProvingKeyT(h);
 }
 
@@ -106,112 +170,155 @@ inline bool pk_bellman2ethsnarks(const std::string &bellman_pk_file, const std::
 // the "domain" of the reference is an evaluation_domain object; here it is a property of the context.
 struct DomainT { uint32_t m; };
 
-// ProverContextT (hpp:279-291): borrows the key, owns device state; one per concurrent prover
+// ProverContextT (hpp:279-291), member for member: borrows the key and (optionally) a constraint system, carries the
+// config and the domain, owns scratch.  The reference's scratch vectors stay empty (the scratch lives in HBM, owned by
+// `ctx`); they are here so that code which sizes or clears them keeps compiling.  One context per concurrent prover.
+typedef std::remove_reference<decltype(std::declval<ProtoboardT &>().constraint_system)>::type ConstraintSystemT_;
 struct ProverContextT {
     ProvingKeyT &provingKey;
+    const ConstraintSystemT_ *constraint_system = nullptr;       // when set it is the system that is proven (else pb.constraint_system)
     libsnark::Config config;
     std::shared_ptr<DomainT> domain;
-    std::shared_ptr<zk_ctx> ctx;
+    std::vector<decltype(std::declval<const FieldT &>().as_bigint())> scratch_exponents;
+    std::vector<FieldT> aA, aB, aH;
+    std::shared_ptr<zk_ctx> ctx;                                  // added: the device-side context, built on first use
     explicit ProverContextT(ProvingKeyT &pk) : provingKey(pk) {}
 };
 
 namespace detail {
 struct Flat { std::vector<uint32_t> ptr, col; std::vector<uint64_t> coeff; };
+// Montgomery limbs of an Fr element for the C ABI
+inline void push_limbs(std::vector<uint64_t> &dst, const FieldT &c) {
+#ifdef ETHSNARKS_HIP_FR_VIA_BIGINT
+    const auto b = c.as_bigint();                                   // canonical; converted in bulk by zk_fr_convert below
+    dst.insert(dst.end(), b.data, b.data + 4);
+#else
+    static_assert(sizeof(FieldT) == 32, "FieldT must be 4 x u64 Montgomery limbs (libff::Fp_model<4>)");
+    const uint64_t *limbs = reinterpret_cast<const uint64_t *>(&c);
+    dst.insert(dst.end(), limbs, limbs + 4);
+#endif
+}
 template <class LC> void push_row(Flat &f, const LC &lc) {
     for (const auto &t : lc.getTerms()) {                          // src/export.cpp:157-171
         f.col.push_back((uint32_t)t.index);
-        const FieldT c = t.getCoeff();
-        const uint64_t *limbs = reinterpret_cast<const uint64_t *>(&c);   // Fp_model<4>: 4 x u64 Montgomery limbs
-        f.coeff.insert(f.coeff.end(), limbs, limbs + 4);
+        push_limbs(f.coeff, t.getCoeff());
     }
     f.ptr.push_back((uint32_t)f.col.size());
 }
-inline void ensure_context(ProverContextT &context, ProtoboardT &pb) {
-    if (context.ctx) return;
-    const auto &cs = pb.constraint_system;
-    Flat A, B, C; A.ptr = B.ptr = C.ptr = {0};
-    for (size_t c = 0; c < cs.num_constraints(); c++) {            // src/export.cpp:183-190
-        push_row(A, cs.constraints[c]->getA()); push_row(B, cs.constraints[c]->getB()); push_row(C, cs.constraints[c]->getC());
+struct FlatSystem {
+    Flat A, B, C; uint32_t nC, nIn, V;
+    template <class CS> explicit FlatSystem(const CS &cs) : nC((uint32_t)cs.num_constraints()), nIn((uint32_t)cs.num_inputs()), V((uint32_t)cs.num_variables()) {
+        A.ptr = B.ptr = C.ptr = {0};
+        for (size_t c = 0; c < cs.num_constraints(); c++) {        // src/export.cpp:183-190
+            push_row(A, cs.constraints[c]->getA()); push_row(B, cs.constraints[c]->getB()); push_row(C, cs.constraints[c]->getC());
+        }
+#ifdef ETHSNARKS_HIP_FR_VIA_BIGINT
+        for (Flat *f : {&A, &B, &C}) zk_check(zk_fr_convert(f->coeff.data(), (uint32_t)(f->coeff.size() / 4), 1));
+#endif
     }
-    zk_csr a{(uint32_t)cs.num_constraints(), A.ptr.data(), A.col.data(), A.coeff.data()};
-    zk_csr b{(uint32_t)cs.num_constraints(), B.ptr.data(), B.col.data(), B.coeff.data()};
-    zk_csr c{(uint32_t)cs.num_constraints(), C.ptr.data(), C.col.data(), C.coeff.data()};
-    zk_config cfg{context.config.multi_exp_c, context.config.device, 0, 1};
+    zk_csr a() const { return zk_csr{nC, A.ptr.data(), A.col.data(), A.coeff.data()}; }
+    zk_csr b() const { return zk_csr{nC, B.ptr.data(), B.col.data(), B.coeff.data()}; }
+    zk_csr c() const { return zk_csr{nC, C.ptr.data(), C.col.data(), C.coeff.data()}; }
+};
+inline void ensure_context(ProverContextT &context, const ProtoboardT &pb) {
+    if (context.ctx) return;
+    const FlatSystem f(context.constraint_system ? *context.constraint_system : pb.constraint_system);
+    const zk_csr a = f.a(), b = f.b(), c = f.c();
+    zk_config cfg{context.config.multi_exp_c, hip_device(), 0, 1};
     zk_ctx *h = nullptr;
-    zk_check(zk_ctx_create(context.provingKey.get(), &a, &b, &c, (uint32_t)cs.num_constraints(), (uint32_t)cs.num_inputs(),
-                           (uint32_t)cs.num_variables(), &cfg, &h));
+    zk_check(zk_ctx_create(context.provingKey.get(), &a, &b, &c, f.nC, f.nIn, f.V, &cfg, &h));
     context.ctx.reset(h, zk_ctx_destroy);
 }
+// pb.values (Fr[V + 1], ONE at index 0) as the C ABI wants it
+struct Witness {
+    std::vector<uint64_t> copy; const uint64_t *ptr; int canonical;
+    explicit Witness(const ProtoboardT &pb) {
+#ifdef ETHSNARKS_HIP_FR_VIA_BIGINT
+        copy.reserve(4 * pb.values.size());
+        for (const auto &v : pb.values) push_limbs(copy, v);
+        ptr = copy.data(); canonical = 1;
+#else
+        ptr = reinterpret_cast<const uint64_t *>(pb.values.data()); canonical = 0;
+#endif
+    }
+};
 }  // namespace detail
 
 // get_domain (src/stubs.cpp:61-75): same size rule; building the context uploads key + CSR and the twiddles
-inline std::shared_ptr<DomainT> get_domain(ProtoboardT &pb, const ProvingKeyT &, const libsnark::Config &) {
+inline const std::shared_ptr<DomainT> get_domain(ProtoboardT &pb, const ProvingKeyT &, const libsnark::Config &) {
     const auto &cs = pb.constraint_system;
     return std::make_shared<DomainT>(DomainT{zk_domain_size((uint32_t)cs.num_constraints(), (uint32_t)cs.num_inputs())});
 }
 
 // prove (src/stubs.cpp:42-47): proof JSON of src/export.cpp:99-121
-inline std::string prove(ProverContextT &context, ProtoboardT &pb) {
-    detail::ensure_context(context, pb);
-    const uint64_t *w = reinterpret_cast<const uint64_t *>(pb.values.data());     // ONE at index 0 (tcc:492-493)
+namespace detail {
+inline std::string prove_const(ProverContextT &context, const ProtoboardT &pb) {
+    ensure_context(context, pb);
+    const Witness w(pb);                                            // ONE at index 0 (tcc:492-493)
     zk_proof proof;
-    zk_check(zk_prove(context.ctx.get(), w, /*canonical=*/0, &proof));
+    zk_check(zk_prove(context.ctx.get(), w.ptr, w.canonical, &proof));
     const uint32_t nIn = (uint32_t)pb.constraint_system.num_inputs();
     size_t len = 0;
-    zk_proof_to_json(&proof, w + 4, nIn, 0, nullptr, 0, &len);
+    zk_proof_to_json(&proof, w.ptr + 4, nIn, w.canonical, nullptr, 0, &len);
     std::string out(len + 1, '\0');
-    zk_check(zk_proof_to_json(&proof, w + 4, nIn, 0, &out[0], out.size(), &len));
+    zk_check(zk_proof_to_json(&proof, w.ptr + 4, nIn, w.canonical, &out[0], out.size(), &len));
     out.resize(len);
     return out;
 }
+}  // namespace detail
+inline std::string prove(ProverContextT &context, ProtoboardT &pb) { return detail::prove_const(context, pb); }
 
-inline std::string stub_prove_from_pb(ProtoboardT &pb, const char *pk_raw) {        // src/pinocchio/main.cpp:41
+namespace detail {
+inline std::string prove_from_pb_const(const ProtoboardT &pb, const char *pk_raw) {
     ProvingKeyT pk = load_proving_key(pk_raw);
     ProverContextT context(pk);
+    context.constraint_system = &pb.constraint_system;
     context.config = libsnark::Config();
-    context.domain = get_domain(pb, pk, context.config);
-    return prove(context, pb);
+    context.domain = std::make_shared<DomainT>(DomainT{zk_domain_size((uint32_t)pb.constraint_system.num_constraints(), (uint32_t)pb.constraint_system.num_inputs())});
+    return prove_const(context, pb);
 }
+inline int genkeys_from_pb_const(const ProtoboardT &pb, const char *pk_file, const char *vk_file);
+}  // namespace detail
+inline std::string stub_prove_from_pb(ProtoboardT &pb, const char *pk_raw) { return detail::prove_from_pb_const(pb, pk_raw); }   // src/pinocchio/main.cpp:41
 
-inline int stub_genkeys_from_pb(ProtoboardT &pb, const char *pk_file, const char *vk_file) {   // src/stubs.cpp:77-87
-    const auto &cs = pb.constraint_system;
-    detail::Flat A, B, C; A.ptr = B.ptr = C.ptr = {0};
-    for (size_t c = 0; c < cs.num_constraints(); c++) {
-        detail::push_row(A, cs.constraints[c]->getA()); detail::push_row(B, cs.constraints[c]->getB()); detail::push_row(C, cs.constraints[c]->getC());
-    }
-    zk_csr a{(uint32_t)cs.num_constraints(), A.ptr.data(), A.col.data(), A.coeff.data()};
-    zk_csr b{(uint32_t)cs.num_constraints(), B.ptr.data(), B.col.data(), B.coeff.data()};
-    zk_csr c{(uint32_t)cs.num_constraints(), C.ptr.data(), C.col.data(), C.coeff.data()};
+inline int stub_genkeys_from_pb(ProtoboardT &pb, const char *pk_file, const char *vk_file) { return detail::genkeys_from_pb_const(pb, pk_file, vk_file); }   // src/stubs.cpp:77-87
+inline int detail::genkeys_from_pb_const(const ProtoboardT &pb, const char *pk_file, const char *vk_file) {
+    const detail::FlatSystem f(pb.constraint_system);
+    const zk_csr a = f.a(), b = f.b(), c = f.c();
     uint64_t toxic[20];
     for (int i = 0; i < 5; i++) {                                   // t, alpha, beta, gamma, delta (tcc:283-287)
         const auto v = FieldT::random_element().as_bigint();
         std::memcpy(toxic + 4 * i, v.data, 32);
     }
     zk_pk *pk = nullptr; zk_vk *vk = nullptr;
-    if (zk_keygen(&a, &b, &c, (uint32_t)cs.num_constraints(), (uint32_t)cs.num_inputs(), (uint32_t)cs.num_variables(), toxic, 0, &pk, &vk) != ZK_OK) return 1;
+    if (zk_keygen(&a, &b, &c, f.nC, f.nIn, f.V, toxic, (int)hip_device(), &pk, &vk) != ZK_OK) return 1;
     size_t len = 0;
     zk_vk_to_json(vk, nullptr, 0, &len);
     std::string js(len + 1, '\0');
     int rc = zk_vk_to_json(vk, &js[0], js.size(), &len);
     if (rc == ZK_OK) { std::ofstream fh(vk_file, std::ios::binary); fh.write(js.data(), (std::streamsize)len); rc = fh ? ZK_OK : ZK_ERR_IO; }
+#if defined(CURVE_MCL_BN128)
+    if (rc == ZK_OK) rc = zk_pk_save_raw(pk, pk_file, ZK_CODEC_MCL_BN128);
+#else
     if (rc == ZK_OK) rc = zk_pk_save_raw(pk, pk_file, ZK_CODEC_ALT_BN128);
+#endif
     zk_pk_free(pk); zk_vk_free(vk);
     return rc == ZK_OK ? 0 : 1;
 }
 
-// stub_test_proof_verify (src/stubs.cpp:135-148): keygen -> prove -> verify in memory.  Unlike the reference it
-// sets up the whole context (the reference leaves constraint_system and domain unset).
-inline bool stub_test_proof_verify(ProtoboardT &pb) {
+// stub_test_proof_verify (src/stubs.hpp:14, src/stubs.cpp:135-148): keygen -> prove -> verify in memory.  Unlike the
+// reference it sets up the whole context (the reference leaves constraint_system and domain unset).
+inline bool stub_test_proof_verify(const ProtoboardT &pb) {
     const char *tmpdir = std::getenv("TMPDIR");
     std::string tmpl = std::string(tmpdir && *tmpdir ? tmpdir : "/tmp") + "/zkhip_pk_XXXXXX";
     const int fd = mkstemp(&tmpl[0]);
     if (fd < 0) return false;
     close(fd);
     const std::string pk_tmp = tmpl, vk_tmp = pk_tmp + ".vk.json";
-    if (stub_genkeys_from_pb(pb, pk_tmp.c_str(), vk_tmp.c_str()) != 0) return false;
+    if (detail::genkeys_from_pb_const(pb, pk_tmp.c_str(), vk_tmp.c_str()) != 0) return false;
     std::ifstream vf(vk_tmp, std::ios::binary);
     const std::string vk((std::istreambuf_iterator<char>(vf)), std::istreambuf_iterator<char>());
-    const std::string proof = stub_prove_from_pb(pb, pk_tmp.c_str());
+    const std::string proof = detail::prove_from_pb_const(pb, pk_tmp.c_str());
     std::remove(pk_tmp.c_str()); std::remove(vk_tmp.c_str());
     return stub_verify(vk.c_str(), proof.c_str());
 }

@@ -200,6 +200,8 @@ int zk_ntt(uint64_t *data, uint32_t logm, int inverse, int coset, int device);
 int zk_witness_map(zk_ctx *ctx, const uint64_t *witness, int canonical, uint64_t *h_out /* (m+1) x 4 */);
 int zk_msm_g1(const uint64_t *bases, const uint64_t *scalars, uint32_t n, uint32_t c, int device, uint64_t out_affine[8]);
 int zk_msm_g2(const uint64_t *bases, const uint64_t *scalars, uint32_t n, uint32_t c, int device, uint64_t out_affine[16]);
+/* host-only: n Fr elements between canonical and Montgomery form, in place (adapters whose field objects are opaque) */
+int zk_fr_convert(uint64_t *io, uint32_t n, int to_montgomery);
 int zk_field_mul(const uint64_t *a, const uint64_t *b, uint64_t *out, uint32_t n, int field /* 0 Fr, 1 Fq */, int device);
 
 #ifdef __cplusplus

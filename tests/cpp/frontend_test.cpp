@@ -8,6 +8,7 @@
 //   frontend_test dump  <r1cs.json> <witness.json>     depth-29 Merkle membership circuit in r1cs2json / witness2json form
 //   frontend_test prove <pk.raw> <vk.json> <proof.json>   keygen + prove + verify of that circuit through the adapter (GPU)
 //   frontend_test roundtrip                            stub_test_proof_verify on the MiMC hash circuit (GPU)
+//   frontend_test context <pk.raw> <vk.json>           the ProverContextT caller sequence of SURVEY section 3 (GPU)
 //   frontend_test verify_cli <vk.json> <proof.json>    stub_main_verify (host only): exit code 0 / 1 / 2 like the reference's
 #include "ethsnarks_hip/stubs.hpp"
 #include "ethsnarks_hip/gadgets.hpp"
@@ -153,10 +154,27 @@ int main(int argc, char **argv) {
             for (int i = 1; i < argc; i++) av.push_back(argv[i]);
             return stub_main_verify("frontend_test", (int)av.size(), av.data());
         }
+        if (mode == "context" && argc == 4) {                 // the caller sequence of SURVEY section 3 (P), member for member
+            ProtoboardT pb;
+            if (!build_mimc_hash(pb)) return 1;
+            if (stub_genkeys_from_pb(pb, argv[2], argv[3]) != 0) return 1;
+            ProvingKeyT pk = load_proving_key(argv[2]);
+            ProverContextT ctx(pk);
+            ctx.constraint_system = &pb.constraint_system;
+            ctx.config = libsnark::Config();
+            ctx.domain = get_domain(pb, pk, ctx.config);
+            const std::string json = prove(ctx, pb);
+            std::ifstream vf(argv[3], std::ios::binary);
+            const std::string vk((std::istreambuf_iterator<char>(vf)), std::istreambuf_iterator<char>());
+            const bool ok = ctx.domain->m == 1024 && stub_verify(vk.c_str(), json.c_str()) && prove(ctx, pb) == json;
+            std::cout << (ok ? "VERIFIED" : "REJECTED") << std::endl;
+            return ok ? 0 : 1;
+        }
         if (mode == "roundtrip") {
             ProtoboardT pb;
             if (!build_mimc_hash(pb)) return 1;
-            const bool ok = stub_test_proof_verify(pb);
+            const ProtoboardT &cpb = pb;                      // stub_test_proof_verify takes a const protoboard (src/stubs.hpp:14)
+            const bool ok = stub_test_proof_verify(cpb);
             std::cout << (ok ? "VERIFIED" : "REJECTED") << std::endl;
             return ok ? 0 : 1;
         }

@@ -90,3 +90,36 @@ def test_adapter_genkeys_prove_verify_matches_oracle(exe, oracle, tmp_path):
 def test_adapter_stub_test_proof_verify(exe):
     p = subprocess.run([exe, "roundtrip"], capture_output=True, text=True)
     assert p.returncode == 0 and p.stdout.strip() == "VERIFIED", p.stdout + p.stderr
+
+
+@pytest.mark.gpu
+def test_adapter_prover_context_call_sequence(exe, tmp_path):
+    """load_proving_key -> ProverContextT ctx(pk); ctx.constraint_system = &pb.constraint_system; ctx.config = Config();
+    ctx.domain = get_domain(...) -> prove(ctx, pb), as SURVEY section 3 reconstructs an ethsnarks caller"""
+    p = subprocess.run([exe, "context", str(tmp_path / "pk.raw"), str(tmp_path / "vk.json")], capture_output=True, text=True)
+    assert p.returncode == 0 and p.stdout.strip() == "VERIFIED", p.stdout + p.stderr
+
+
+@pytest.fixture(scope="module")
+def exe_libsnark_branch(tmp_path_factory):
+    """the adapter's `libsnark is on the include path` branch, compiled against the API double of tests/cpp/libsnark_api_double"""
+    out = str(tmp_path_factory.mktemp("cpp2") / "libsnark_branch_test")
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+           "-I" + os.path.join(ROOT, "tests", "cpp", "libsnark_api_double"), "-I" + os.path.join(ROOT, "tests", "cpp"),
+           os.path.join(ROOT, "tests", "cpp", "libsnark_branch_test.cpp"), "-o", out,
+           "-L" + os.path.join(ROOT, "ethsnarks_amd"), "-lzkhip", "-Wl,-rpath," + os.path.join(ROOT, "ethsnarks_amd")]
+    p = subprocess.run(cmd, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    return out
+
+
+def test_libsnark_branch_compiles_and_config_is_source_compatible(exe_libsnark_branch):
+    p = subprocess.run([exe_libsnark_branch, "compile-only"], capture_output=True, text=True)
+    assert p.returncode == 0 and p.stdout.strip() == "OK", p.stdout + p.stderr
+
+
+@pytest.mark.gpu
+def test_libsnark_branch_proves_and_verifies(exe_libsnark_branch, tmp_path):
+    p = subprocess.run([exe_libsnark_branch, "prove", str(tmp_path / "pk.raw"), str(tmp_path / "vk.json"), str(tmp_path / "proof.json")],
+                       capture_output=True, text=True)
+    assert p.returncode == 0 and p.stdout.strip() == "OK", p.stdout + p.stderr
