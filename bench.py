@@ -55,6 +55,9 @@ def main():
     ap.add_argument("--multi-exp-c", type=int, default=0)
     ap.add_argument("--inflight", type=int, default=3,
                     help="prover contexts kept in flight per GPU (1 = one synchronous proof at a time)")
+    ap.add_argument("--batch", type=int, default=1,
+                    help="proofs per launch sequence (zk_prove_batch): a step then proves this many witnesses of the circuit; "
+                         "what the latency-sized workloads need (one small proof alone is ~50 launches of latency-bound kernels)")
     ap.add_argument("--witness", choices=["resident", "host"], default="resident",
                     help="where the witness lives when the timed region starts (`value` is quoted on resident)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -124,10 +127,12 @@ def main():
 
     def run_leg(pk, r1cs, wm, shard, steps, warmup, witness):
         """`warmup` untimed + `steps` timed proofs in one parallelisation"""
+        kb = max(1, args.batch) if not shard else 1
         ctxs = [P.ProverContext(pk, r1cs, multi_exp_c=args.multi_exp_c, device=local_rank,
-                                shard_rank=rank if shard else 0, shard_count=world if shard else 1)
+                                shard_rank=rank if shard else 0, shard_count=world if shard else 1, max_batch=kb)
                 for _ in range(max(1, args.inflight))]
-        d_w = torch.from_numpy(np.ascontiguousarray(wm).view(np.int64).copy()).cuda() if witness == "resident" else None
+        wmk = np.ascontiguousarray(np.tile(np.ascontiguousarray(wm).reshape(1, -1), (kb, 1)))     # the batch: kb witnesses, contiguous
+        d_w = torch.from_numpy(wmk.view(np.int64).copy()).cuda() if witness == "resident" else None
         sharded = [ShardedProver(c, dist, torch.device("cuda", local_rank)) for c in ctxs] if (shard and not gloo) else None
         gather_buf = torch.empty((world, 640), dtype=torch.uint8) if (shard and gloo) else None
         acc_b, pending, state = [], [], {"t": {}}
@@ -140,6 +145,9 @@ def main():
                 proof = ctxs[slot].prove_combine(gather_buf.numpy().reshape(-1).view(np.uint64))
             elif shard:
                 proof, tm = sharded[slot].finish()
+            elif kb > 1:
+                parts, tm = ctxs[slot].collect_batch(kb)
+                proof = ctxs[slot].prove_combine(parts[kb - 1])
             else:
                 part, tm = ctxs[slot].collect()
                 proof = ctxs[slot].prove_combine(part)
@@ -153,7 +161,9 @@ def main():
                 if len(pending) == len(ctxs):
                     js = finish(pending.pop(0))
                 slot = i % len(ctxs)
-                if d_w is not None:
+                if kb > 1:
+                    ctxs[slot].submit_batch(wmk, device_ptr=d_w.data_ptr() if d_w is not None else None, k=kb)
+                elif d_w is not None:
                     ctxs[slot].submit_resident(d_w.data_ptr())
                 else:
                     ctxs[slot].submit(wm)
@@ -171,15 +181,15 @@ def main():
         js = run(steps)
         sync()
         elapsed = time.perf_counter() - t0
-        launches = (P.launch_count() - n0) / float(steps)
+        launches = (P.launch_count() - n0) / float(steps * kb)
         if dist is not None:
             tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if gloo else torch.device("cuda", local_rank))
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
-        proofs = steps * (world if (world > 1 and not shard) else 1)
+        proofs = steps * kb * (world if (world > 1 and not shard) else 1)
         info = ctxs[0].info()
         ksum = None
-        if rank == 0 and not args.no_extras and not shard:
+        if rank == 0 and not args.no_extras and not shard and kb == 1:
             # one more (untimed) proof with every launch bracketed by HIP events: sum of kernel durations per proof
             P.profile_begin()
             ctxs[0].submit_resident(d_w.data_ptr()) if d_w is not None else ctxs[0].submit(wm)
@@ -238,16 +248,17 @@ def main():
         nB_local = pk.nB // world if shard else pk.nB
         kern_ms = float(np.mean(acc_b)) if acc_b else float("nan")
         W = info["B"]["W"]                                              # the windows the B-query context really uses (zk_ctx_info)
-        alg_bytes = 160.0 * nB_local                                   # 128 B G2 base + 32 B scalar per pair
+        kb = max(1, args.batch) if not shard else 1
+        alg_bytes = (128.0 + 32.0 * kb) * nB_local                     # one launch: 128 B per G2 base + 32 B per scalar of each of its kb proofs
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-        mads = float(MADS_PER_G2_MADD) * nB_local * W
+        mads = float(MADS_PER_G2_MADD) * nB_local * W * kb
         mad_peak = MAD_LANE_OPS_PER_CLK_CU * devinfo["compute_units"] * devinfo["clock_mhz"] * 1e6
         bytes_per_proof = proof_bytes(r1cs, pk, m)
         traffic, traffic_src = pmc_traffic("k_msm_accumulate<G2, 1>", args.workload, logm, world if shard else 1)
         out = {
             "metric": "groth16_proofs_per_sec", "value": round(value, 4), "unit": "proofs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,      # a step = config.proofs_per_step proofs
             "scaling": "strong" if shard else "weak", "vs_baseline": None,
             "dtype": "u32 (8-limb 254-bit Montgomery integers)", "data": "synthetic",
             "constraints_per_sec": round(value * nC, 1),
@@ -255,7 +266,7 @@ def main():
                        "parallelism": ("msm-shard%d+allgather640B" % world) if shard else ("replicas%d" % world if world > 1 else "1gpu"),
                        "multi_exp_c": info["B"]["c"], "windows": W,
                        "witness": "resident in HBM when the timed region starts" if args.witness == "resident" else "host buffer, H2D inside the timed region",
-                       "inflight": max(1, args.inflight), "device": devinfo},
+                       "inflight": max(1, args.inflight), "proofs_per_step": max(1, args.batch) if not shard else 1, "device": devinfo},
             "roofline": {"kernel": "k_msm_accumulate<G2, 1> (B-query bucket accumulation)", "bound": "hbm",
                          "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic, "traffic_source": traffic_src,

@@ -61,10 +61,10 @@ struct SortShape {
         if (const char *e = getenv("ZK_SORT_PER_GROUP")) { int v = atoi(e); if (v >= 64) per_group = (uint32_t)v; }   // tuning aid
         resize(n, nb);
     }
-    void resize(uint32_t n, uint32_t nb) {            // same bins and per_group for another scalar count (proving path: no getenv)
-        cb = nb < SORT_MAX_CB ? nb : SORT_MAX_CB;
-        fb = nb / cb;
-        fine_bits = 0; while ((1u << fine_bits) < fb) fine_bits++;
+    void resize(uint32_t n, uint32_t nb) {            // same per_group for another scalar / bucket count (proving path: no getenv)
+        fine_bits = 0; while (((nb + (1u << fine_bits) - 1) >> fine_bits) > SORT_MAX_CB) fine_bits++;
+        fb = 1u << fine_bits;                               // fine buckets per coarse bin (a power of two)
+        cb = (nb + fb - 1) >> fine_bits;                    // coarse bins; the last one may be partly filled (batches that are not a power of two)
         groups = (n + per_group - 1) / per_group; if (!groups) groups = 1;
     }
 };
@@ -109,7 +109,8 @@ struct MsmShape {
             if ((uint64_t)n * (254 / c + 1) >= ((uint64_t)MSM_SEG_MIN << (c - 1))) return c;
         return 2;
     }
-    void set(uint32_t n_, uint32_t c_) {
+    // batch: proofs per launch sequence the MSM will see (the latency / throughput switches below look at all their entries)
+    void set(uint32_t n_, uint32_t c_, uint32_t batch = 1) {
         n = n_; c = c_ ? c_ : pick_c(n_);
         if (c < 2) c = 2;
         if (c > 20) c = 20;
@@ -117,11 +118,12 @@ struct MsmShape {
         group = msm_group(nb);
         // measured (tools/dev_small_sweep.sh, domains 2^13 .. 2^19): quad reductions win up to 2^17 constraints with one or
         // three proofs in flight (and still for a single proof beyond); quad accumulation only while the GPU is mostly idle
-        quad = max_entries() <= (1ull << 21) ? 4 : 1;
-        quad_acc = max_entries() <= (1ull << 17) ? 4 : 1;
+        const uint64_t all = max_entries() * (batch ? batch : 1);
+        quad = all <= (1ull << 21) ? 4 : 1;
+        quad_acc = all <= (1ull << 17) ? 4 : 1;
         if (const char *e = getenv("ZK_MSM_QUAD")) quad = atoi(e) ? 4 : 1;                                           // tuning aids
         if (const char *e = getenv("ZK_MSM_QUAD_ACC")) quad_acc = atoi(e) ? 4 : 1;
-        chunk.seg_min = max_entries() <= (1ull << 23) ? MSM_SEG_MIN_SMALL : MSM_SEG_MIN;
+        chunk.seg_min = all <= (1ull << 23) ? MSM_SEG_MIN_SMALL : MSM_SEG_MIN;
         chunk.seg_max = MSM_SEG_MAX;
         if (const char *e = getenv("ZK_SEG_MIN")) { int v = atoi(e); if (v >= 4) chunk.seg_min = (uint32_t)v; }    // tuning aids
         if (const char *e = getenv("ZK_SEG_MAX")) { int v = atoi(e); if (v >= 4) chunk.seg_max = (uint32_t)v; }
@@ -138,15 +140,21 @@ struct MsmShape {
 // MSM's table ([w][remap_src] layout, scalar i) and this MSM covers scalars [remap_offset, remap_offset + n)
 struct SortView {
     const uint32_t *sorted = nullptr, *off = nullptr;   // off[b] = entries before bucket b, off[nb] = all entries
-    uint32_t nb = 0, entries_bound = 0;             // entries_bound: upper bound of sorted entries (n_src * W)
+    uint32_t nb = 0, entries_bound = 0;             // nb: buckets of the sort (batch x per-proof buckets); entries_bound: upper bound of sorted entries (batch x n_src x W)
+    uint32_t batch = 1;                             // proofs sorted together: bucket id = proof * (nb / batch) + digit bucket
     uint32_t remap_src = 0, remap_offset = 0;
     const uint32_t *remap_pos = nullptr;            // optional scalar index -> own base index (0xffffffff: absent); else i - remap_offset
 };
 
+// Several proofs of ONE circuit through one launch sequence: `batch` scalar vectors over the same bases.
+// The sort key becomes (proof, bucket) -- bucket id = proof * nb + digit bucket, so the k bucket sets lie side by side --
+// and every kernel simply sees k times the entries, buckets, groups and partial sums; the table is shared.
 template <class C>
 struct MsmWork {
     MsmShape sh;
     SortShape ss;
+    uint32_t max_batch = 1;                     // capacity: proofs per launch sequence the buffers are sized for
+    uint32_t cur_batch = 1;                     // ... and of the reduction in flight
     typename C::Affine *table = nullptr;        // [W][table_n] window multiples of the bases, resident for the context's life
     uint32_t table_n = 0;
     bool owns_table = true;                     // false: the table belongs to a DeviceTables entry shared by several contexts
@@ -155,8 +163,9 @@ struct MsmWork {
     uint32_t *off = nullptr, *sorted = nullptr;
     uint32_t *heavy_list = nullptr, *heavy_count = nullptr;
     typename C::XYZZ *segsum = nullptr, *bucket = nullptr, *partial_a = nullptr, *partial_b = nullptr;
-    typename C::XYZZ *host_result = nullptr;    // pinned, 1 entry
-    typename C::XYZZ *dev_result = nullptr;     // optional: a device copy of the result as well (sharded provers exchange it with RCCL)
+    typename C::XYZZ *host_result = nullptr;    // pinned, max_batch entries
+    typename C::XYZZ *dev_result = nullptr;     // optional: a device copy of the results as well, one every dev_result_pitch bytes (sharded provers exchange it with RCCL)
+    size_t dev_result_pitch = 0;
     hipEvent_t ev_acc0 = nullptr, ev_acc1 = nullptr;   // bracket k_msm_accumulate (the dominant kernel) on its stream
     float accumulate_ms() const { float ms = 0; if (ev_acc0 && ev_acc1) hipEventElapsedTime(&ms, ev_acc0, ev_acc1); return ms; }
 
@@ -165,23 +174,25 @@ struct MsmWork {
     // witness): take that shape (same c, W, buckets, segment length), size the reduction buffers for its entries,
     // and do not allocate sort buffers of its own.
     // sort_only: no table and no reduction buffers -- this object only sorts a scalar vector for others.
-    int alloc(uint32_t n, uint32_t c, typename C::Affine *shared_table = nullptr, const MsmShape *sort_like = nullptr, bool sort_only = false);
+    int alloc(uint32_t n, uint32_t c, typename C::Affine *shared_table = nullptr, const MsmShape *sort_like = nullptr, bool sort_only = false, uint32_t batch = 1);
     void release();
     // table <- window multiples of d_bases[0..n) (device pointer); once per context
     int precompute(const typename C::Affine *d_bases, uint32_t n, hipStream_t st);
     // enqueue the MSM: sort + accumulation (machine-filling) on `st`, the low-parallelism bucket reduction on
     // `st_tail` (may equal st); the result lands in host_result after st_tail drains
-    int enqueue(const fe *scalars, const uint32_t *gather, uint32_t n, int canonical, hipStream_t st, hipStream_t st_tail);
+    // batch > 1: proof p reads scalars[p * stride + (gather ? gather[i] : i)]
+    int enqueue(const fe *scalars, const uint32_t *gather, uint32_t n, int canonical, hipStream_t st, hipStream_t st_tail, uint32_t batch = 1, uint32_t stride = 0);
     // the two halves: the bucket sort of this MSM's scalars, and accumulation + reduction driven by a sort view
-    int enqueue_sort(const fe *scalars, const uint32_t *gather, uint32_t n, int canonical, hipStream_t st);
+    int enqueue_sort(const fe *scalars, const uint32_t *gather, uint32_t n, int canonical, hipStream_t st, uint32_t batch = 1, uint32_t stride = 0);
     int enqueue_reduce(const SortView &v, hipStream_t st, hipStream_t st_tail);
     template <int Q> int launch_reduce(uint32_t K, uint32_t groups, hipStream_t st);
     uint32_t tree_levels(uint32_t groups) const;
     const uint32_t *cur_off = nullptr;          // bucket offsets of the sort driving the current reduction
-    SortView view() const { SortView v; v.sorted = sorted; v.off = off; v.nb = sh.nb; v.entries_bound = (uint32_t)((uint64_t)table_n * sh.W); return v; }
+    uint32_t sort_batch = 1;                    // batch of the last enqueue_sort
+    SortView view() const { SortView v; v.sorted = sorted; v.off = off; v.batch = sort_batch; v.nb = sh.nb * sort_batch; v.entries_bound = (uint32_t)((uint64_t)table_n * sh.W * sort_batch); return v; }
     // view for an MSM over scalars [offset, offset + n_dst) of THIS sort (its table has stride n_dst)
     SortView view_for(uint32_t offset, const uint32_t *pos = nullptr) const { SortView v = view(); v.remap_src = table_n; v.remap_offset = offset; v.remap_pos = pos; return v; }
-    typename C::XYZZ finish() const { return C::canon(*host_result); }   // device values are loose ([0, 2p)): normalise once
+    typename C::XYZZ finish(uint32_t proof = 0) const { return C::canon(host_result[proof]); }   // device values are loose ([0, 2p)): normalise once
 };
 
 }  // namespace zk

@@ -44,26 +44,29 @@ static ZK_D uint32_t msm_digit(const fe &s, uint32_t w, uint32_t c, uint32_t &ca
     if (d > nb) { d = full - d; neg = 1; carry = 1; }         // digit in [-2^(c-1)+1, 2^(c-1)]
     return d;
 }
-static ZK_D fe msm_load_scalar(const fe *__restrict__ scalars, const uint32_t *__restrict__ gather, uint32_t i, int canonical) {
-    fe s = scalars[gather ? gather[i] : i];                    // scalar i of this MSM; Montgomery unless canonical
+// scalar il of proof p: Montgomery unless canonical
+static ZK_D fe msm_load_scalar(const fe *__restrict__ scalars, const uint32_t *__restrict__ gather, uint32_t p, uint32_t stride, uint32_t il, int canonical) {
+    fe s = scalars[(size_t)p * stride + (gather ? gather[il] : il)];
     return canonical ? s : Fr::from_mont(s);
 }
 
 // counts[bin * groups + group] = entries of this workgroup's scalars that fall into coarse bin `bin`
 template <class C>
 __global__ void __launch_bounds__(SORT_THREADS)
-k_sort_count(const fe *__restrict__ scalars, const uint32_t *__restrict__ gather, uint32_t n, int canonical,
+k_sort_count(const fe *__restrict__ scalars, const uint32_t *__restrict__ gather, uint32_t n, uint32_t batch, uint32_t stride, int canonical,
              uint32_t c, uint32_t W, SortShape ss, uint32_t *__restrict__ counts) {
     __shared__ uint32_t cnt[SORT_MAX_CB];
     for (uint32_t k = threadIdx.x; k < ss.cb; k += blockDim.x) cnt[k] = 0;
     __syncthreads();
-    const uint32_t i0 = blockIdx.x * ss.per_group, i1 = (i0 + ss.per_group < n) ? i0 + ss.per_group : n;
+    const uint32_t total = n * batch, nbp = 1u << (c - 1);     // scalars of all proofs; buckets per proof
+    const uint32_t i0 = blockIdx.x * ss.per_group, i1 = (i0 + ss.per_group < total) ? i0 + ss.per_group : total;
     for (uint32_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
-        const fe s = msm_load_scalar(scalars, gather, i, canonical);
+        const uint32_t p = i / n, il = i - p * n;
+        const fe s = msm_load_scalar(scalars, gather, p, stride, il, canonical);
         uint32_t carry = 0, neg;
         for (uint32_t w = 0; w < W; w++) {
             uint32_t d = msm_digit(s, w, c, carry, neg);
-            if (d) atomicAdd(&cnt[(d - 1) >> ss.fine_bits], 1u);
+            if (d) atomicAdd(&cnt[(p * nbp + d - 1) >> ss.fine_bits], 1u);
         }
     }
     __syncthreads();
@@ -114,21 +117,24 @@ k_sort_binscan(const uint32_t *__restrict__ bin_total, uint32_t cb, uint32_t *__
 // pass 1 scatter: (bucket, payload) pairs into the coarse-bin regions, LDS-ranked
 template <class C>
 __global__ void __launch_bounds__(SORT_THREADS)
-k_sort_partition(const fe *__restrict__ scalars, const uint32_t *__restrict__ gather, uint32_t n, int canonical,
+k_sort_partition(const fe *__restrict__ scalars, const uint32_t *__restrict__ gather, uint32_t n, uint32_t batch, uint32_t stride, int canonical,
                  uint32_t c, uint32_t W, SortShape ss, const uint32_t *__restrict__ counts,
                  const uint32_t *__restrict__ bin_base, uint2 *__restrict__ pairs) {
     __shared__ uint32_t pos[SORT_MAX_CB];
     for (uint32_t k = threadIdx.x; k < ss.cb; k += blockDim.x) pos[k] = bin_base[k] + counts[(size_t)k * ss.groups + blockIdx.x];
     __syncthreads();
-    const uint32_t i0 = blockIdx.x * ss.per_group, i1 = (i0 + ss.per_group < n) ? i0 + ss.per_group : n;
+    const uint32_t total = n * batch, nbp = 1u << (c - 1);
+    const uint32_t i0 = blockIdx.x * ss.per_group, i1 = (i0 + ss.per_group < total) ? i0 + ss.per_group : total;
     for (uint32_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
-        const fe s = msm_load_scalar(scalars, gather, i, canonical);
+        const uint32_t pr = i / n, il = i - pr * n;
+        const fe s = msm_load_scalar(scalars, gather, pr, stride, il, canonical);
         uint32_t carry = 0, neg;
         for (uint32_t w = 0; w < W; w++) {
             uint32_t d = msm_digit(s, w, c, carry, neg);
             if (!d) continue;
-            uint32_t p = atomicAdd(&pos[(d - 1) >> ss.fine_bits], 1u);
-            uint2 e; e.x = (w * n + i) | (neg << 31); e.y = d - 1;      // table index of 2^(cw) P_i, sign; bucket
+            const uint32_t b = pr * nbp + d - 1;                        // (proof, bucket)
+            uint32_t p = atomicAdd(&pos[b >> ss.fine_bits], 1u);
+            uint2 e; e.x = (w * n + il) | (neg << 31); e.y = b;         // table index of 2^(cw) P_il, sign; bucket
             pairs[p] = e;
         }
     }
@@ -139,7 +145,7 @@ k_sort_partition(const fe *__restrict__ scalars, const uint32_t *__restrict__ ga
 // slot of the CU it runs on.
 template <class C>
 __global__ void __launch_bounds__(SORT_FINE_THREADS)
-k_sort_fine(const uint2 *__restrict__ pairs, const uint32_t *__restrict__ bin_base, SortShape ss,
+k_sort_fine(const uint2 *__restrict__ pairs, const uint32_t *__restrict__ bin_base, SortShape ss, uint32_t nb,
             uint32_t *__restrict__ off, uint32_t *__restrict__ sorted) {
     __shared__ uint32_t cnt[SORT_MAX_FB], cur[SORT_MAX_FB], sh[SORT_FINE_THREADS];
     const uint32_t bin = blockIdx.x, r0 = bin_base[bin], r1 = bin_base[bin + 1], t = threadIdx.x, T = blockDim.x;
@@ -163,10 +169,11 @@ k_sort_fine(const uint2 *__restrict__ pairs, const uint32_t *__restrict__ bin_ba
     uint32_t ex = sh[t] - sum;
     for (uint32_t k = k0; k < k1; k++) {
         const uint32_t b = bin * ss.fb + k;
-        off[b] = r0 + ex; cur[k] = r0 + ex;
+        if (b < nb) off[b] = r0 + ex;                       // (the last coarse bin may reach past the last bucket)
+        cur[k] = r0 + ex;
         ex += cnt[k];
     }
-    if (bin + 1 == gridDim.x && t == 0) off[(bin + 1) * ss.fb] = r1;   // off[nb] = all entries
+    if (bin + 1 == gridDim.x && t == 0) off[nb] = r1;       // all entries
     __syncthreads();
     for (uint32_t e = r0 + t; e < r1; e += T) {
         const uint2 pr = pairs[e];
@@ -285,24 +292,26 @@ k_msm_heavy(const typename C::XYZZ *__restrict__ piece, const uint32_t *__restri
 // thread / quad per group of K consecutive buckets:  sum_j (g*K + j + 1) * B_{g*K+j}
 template <class C, int Q>
 __global__ void __launch_bounds__(64, C::WAVES_PER_SIMD / 2)
-k_msm_group_reduce(const typename C::XYZZ *__restrict__ bucket, uint32_t nb, uint32_t K,
+k_msm_group_reduce(const typename C::XYZZ *__restrict__ bucket, uint32_t nb, uint32_t K, uint32_t groups_per_proof,
                    typename C::XYZZ *__restrict__ partial) {
     const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x, g = gt / Q, ql = gt % Q;
-    if (g >= nb / K) return;
+    if (g >= nb / K) return;                                   // nb: buckets of all proofs of the batch
     const typename C::XYZZ *B = bucket + (size_t)g * K;
     typename C::XYZZ run = C::infinity(), acc = C::infinity();
     for (uint32_t j = K; j-- > 0;) { run = C::template addQ<Q>(run, B[j], ql); acc = C::template addQ<Q>(acc, run, ql); }
-    if (g) acc = C::template addQ<Q>(acc, C::template mul_smallQ<Q>(run, g * K, ql), ql);
+    const uint32_t gl = g % groups_per_proof;                  // the weights restart with every proof's bucket set
+    if (gl) acc = C::template addQ<Q>(acc, C::template mul_smallQ<Q>(run, gl * K, ql), ql);
     if (ql == 0) partial[g] = acc;
 }
 
 // out[blockIdx] = sum of in[blockIdx*T .. +T) (bounded by count), T = msm_tree_fan(Q) logical threads of Q lanes:
-// LDS tree, upper half parks
+// LDS tree, upper half parks.  blockIdx.y = proof of a batch: its `count` inputs and gridDim.x outputs lie side by side.
 template <class C, int Q>
 __global__ void __launch_bounds__(MSM_TREE)
 k_msm_tree_sum(const typename C::XYZZ *__restrict__ in, uint32_t count, typename C::XYZZ *__restrict__ out) {
     constexpr uint32_t T = MSM_TREE / Q;
     __shared__ typename C::XYZZ sh[T / 2];
+    in += (size_t)blockIdx.y * count; out += (size_t)blockIdx.y * gridDim.x;
     const uint32_t lt = threadIdx.x / Q, ql = threadIdx.x % Q;
     const uint32_t i = blockIdx.x * T + lt;
     typename C::XYZZ acc = i < count ? in[i] : C::infinity();
@@ -317,31 +326,35 @@ k_msm_tree_sum(const typename C::XYZZ *__restrict__ in, uint32_t count, typename
 
 // -------------------------------------------------------------------------------------------------
 template <class C>
-int MsmWork<C>::alloc(uint32_t n, uint32_t c, typename C::Affine *shared_table, const MsmShape *sort_like, bool sort_only) {
-    if (sort_like) sh = *sort_like; else sh.set(n ? n : 1, c);
+int MsmWork<C>::alloc(uint32_t n, uint32_t c, typename C::Affine *shared_table, const MsmShape *sort_like, bool sort_only, uint32_t batch) {
+    max_batch = batch ? batch : 1;
+    if (sort_like) sh = *sort_like; else sh.set(n ? n : 1, c, max_batch);
     sh.set_slots(C::WAVES_PER_SIMD);
-    if (sh.max_entries() >= (1ull << 31)) return fail_msg(ZK_ERR_ARG, "MSM too large: n * windows must stay below 2^31 (entry payload = table index | sign)");
+    const uint64_t B = max_batch;
+    if (sh.max_entries() * B >= (1ull << 31)) return fail_msg(ZK_ERR_ARG, "MSM too large: proofs * n * windows must stay below 2^31 (entry payload = table index | sign)");
+    if ((uint64_t)sh.nb * B > (uint64_t)SORT_MAX_CB * SORT_MAX_FB) return fail_msg(ZK_ERR_ARG, "batch too large: proofs * buckets exceeds the sort's 2^20 buckets");
     const uint32_t G0 = sh.group, K = sh.nb < G0 ? sh.nb : G0, groups = sh.nb / K;
     if (sort_only) { owns_table = false; table_n = n; }
     else if (shared_table) { table = shared_table; owns_table = false; table_n = n; }
     else ZK_HIP(hipMalloc(&table, sizeof(typename C::Affine) * (size_t)(n ? n : 1) * sh.W));
-    ss.set(sh.n, sh.nb);
+    ss.set((uint32_t)(sh.n * B), (uint32_t)(sh.nb * B));            // sized for a full batch (the bins of a smaller batch are re-derived per call)
     if (!sort_like) {
-        ZK_HIP(hipMalloc(&pairs, sizeof(uint2) * sh.max_entries()));
-        ZK_HIP(hipMalloc(&counts, sizeof(uint32_t) * ((size_t)ss.cb * ss.groups + 1)));
+        ZK_HIP(hipMalloc(&pairs, sizeof(uint2) * sh.max_entries() * B));
+        ZK_HIP(hipMalloc(&counts, sizeof(uint32_t) * ((size_t)SORT_MAX_CB * ss.groups + 1)));
         ZK_HIP(hipMalloc(&bin_total, sizeof(uint32_t) * (SORT_MAX_CB + 1)));
         ZK_HIP(hipMalloc(&bin_base, sizeof(uint32_t) * (SORT_MAX_CB + 1)));
-        ZK_HIP(hipMalloc(&sorted, sizeof(uint32_t) * sh.max_entries()));
-        ZK_HIP(hipMalloc(&off, sizeof(uint32_t) * (sh.nb + 1)));
+        ZK_HIP(hipMalloc(&sorted, sizeof(uint32_t) * sh.max_entries() * B));
+        ZK_HIP(hipMalloc(&off, sizeof(uint32_t) * (sh.nb * B + 1)));
     }
     if (sort_only) return ZK_OK;
-    ZK_HIP(hipMalloc(&heavy_list, sizeof(uint32_t) * (sh.max_pieces() / MSM_HEAVY + 2)));
+    const uint64_t pieces = sh.chunk.max_chunks(sh.max_entries() * B) + sh.nb * B + 1;
+    ZK_HIP(hipMalloc(&heavy_list, sizeof(uint32_t) * (pieces / MSM_HEAVY + 2)));
     ZK_HIP(hipMalloc(&heavy_count, sizeof(uint32_t)));
-    ZK_HIP(hipMalloc(&segsum, sizeof(typename C::XYZZ) * sh.max_pieces()));
-    ZK_HIP(hipMalloc(&bucket, sizeof(typename C::XYZZ) * sh.nb));
-    ZK_HIP(hipMalloc(&partial_a, sizeof(typename C::XYZZ) * (groups + 1)));
-    ZK_HIP(hipMalloc(&partial_b, sizeof(typename C::XYZZ) * (zk_div_up(groups, MSM_TREE / sh.quad) + 1)));
-    ZK_HIP(hipHostMalloc(&host_result, sizeof(typename C::XYZZ), hipHostMallocDefault));
+    ZK_HIP(hipMalloc(&segsum, sizeof(typename C::XYZZ) * pieces));
+    ZK_HIP(hipMalloc(&bucket, sizeof(typename C::XYZZ) * sh.nb * B));
+    ZK_HIP(hipMalloc(&partial_a, sizeof(typename C::XYZZ) * ((size_t)groups * B + 1)));
+    ZK_HIP(hipMalloc(&partial_b, sizeof(typename C::XYZZ) * ((size_t)zk_div_up(groups, MSM_TREE / sh.quad) * B + 1)));
+    ZK_HIP(hipHostMalloc(&host_result, sizeof(typename C::XYZZ) * B, hipHostMallocDefault));
     ZK_HIP(hipEventCreate(&ev_acc0)); ZK_HIP(hipEventCreate(&ev_acc1));
     return ZK_OK;
 }
@@ -367,16 +380,18 @@ int MsmWork<C>::precompute(const typename C::Affine *d_bases, uint32_t n, hipStr
 }
 
 template <class C>
-int MsmWork<C>::enqueue_sort(const fe *scalars, const uint32_t *gather, uint32_t n, int canonical, hipStream_t st) {
+int MsmWork<C>::enqueue_sort(const fe *scalars, const uint32_t *gather, uint32_t n, int canonical, hipStream_t st, uint32_t batch, uint32_t stride) {
     if (n != table_n || !sorted) return fail_msg(ZK_ERR_ARG, "MSM sort: scalar count differs from the table's base count");   // the table stride is the precompute-time n
-    const uint32_t c = sh.c, W = sh.W, nb = sh.nb;
-    SortShape sq = ss; sq.resize(n ? n : 1, nb);                // same bins; workgroups sized for this call's n
-    ZK_LAUNCH_SYNC(k_sort_count<C>, sq.groups, SORT_THREADS, st, scalars, gather, n, canonical, c, W, sq, counts);
+    if (!batch || batch > max_batch) return fail_msg(ZK_ERR_ARG, "MSM sort: batch exceeds the capacity the context was created with");
+    sort_batch = batch;
+    const uint32_t c = sh.c, W = sh.W, nb = sh.nb * batch;      // buckets of the whole batch
+    SortShape sq = ss; sq.resize(n * batch ? n * batch : 1, nb);   // bins and workgroups for this call's scalars
+    ZK_LAUNCH_SYNC(k_sort_count<C>, sq.groups, SORT_THREADS, st, scalars, gather, n, batch, stride, canonical, c, W, sq, counts);
     ZK_LAUNCH_SYNC(k_sort_colscan<C>, sq.cb, SORT_THREADS, st, counts, sq.groups, bin_total);
     ZK_LAUNCH_SYNC(k_sort_binscan<C>, 1, SORT_THREADS, st, (const uint32_t *)bin_total, sq.cb, bin_base);
-    ZK_LAUNCH_SYNC(k_sort_partition<C>, sq.groups, SORT_THREADS, st, scalars, gather, n, canonical, c, W, sq,
+    ZK_LAUNCH_SYNC(k_sort_partition<C>, sq.groups, SORT_THREADS, st, scalars, gather, n, batch, stride, canonical, c, W, sq,
                    (const uint32_t *)counts, (const uint32_t *)bin_base, pairs);
-    ZK_LAUNCH_SYNC(k_sort_fine<C>, sq.cb, SORT_FINE_THREADS, st, (const uint2 *)pairs, (const uint32_t *)bin_base, sq, off, sorted);
+    ZK_LAUNCH_SYNC(k_sort_fine<C>, sq.cb, SORT_FINE_THREADS, st, (const uint2 *)pairs, (const uint32_t *)bin_base, sq, nb, off, sorted);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
@@ -392,17 +407,17 @@ uint32_t MsmWork<C>::tree_levels(uint32_t groups) const {
 // bucket reduction with Q lanes per logical thread
 template <class C>
 template <int Q>
-int MsmWork<C>::launch_reduce(uint32_t K, uint32_t groups, hipStream_t st) {
-    const uint32_t nb = sh.nb;
+int MsmWork<C>::launch_reduce(uint32_t K, uint32_t groups, hipStream_t st) {      // groups: per proof
+    const uint32_t nb = sh.nb * cur_batch, all_groups = groups * cur_batch;
     ZK_LAUNCH((k_msm_bucket_finalize<C, Q>), zk_div_up((uint64_t)nb * Q, 64), 64, st, (const typename C::XYZZ *)segsum, (const uint32_t *)cur_off, nb, sh.chunk, bucket, heavy_list, heavy_count);
     ZK_LAUNCH_SYNC((k_msm_heavy<C, Q>), MSM_HEAVY_GRID, 128 * Q, st, (const typename C::XYZZ *)segsum, (const uint32_t *)cur_off, nb, sh.chunk,
                    (const uint32_t *)heavy_list, (const uint32_t *)heavy_count, bucket);
-    ZK_LAUNCH((k_msm_group_reduce<C, Q>), zk_div_up((uint64_t)groups * Q, 64), 64, st, (const typename C::XYZZ *)bucket, nb, K, partial_a);
+    ZK_LAUNCH((k_msm_group_reduce<C, Q>), zk_div_up((uint64_t)all_groups * Q, 64), 64, st, (const typename C::XYZZ *)bucket, nb, K, groups, partial_a);
     typename C::XYZZ *cur = partial_a, *nxt = partial_b;
     uint32_t count = groups;
     do {
         uint32_t outc = zk_div_up(count, MSM_TREE / Q);
-        ZK_LAUNCH_SYNC((k_msm_tree_sum<C, Q>), outc, MSM_TREE, st, (const typename C::XYZZ *)cur, count, nxt);
+        ZK_LAUNCH_SYNC((k_msm_tree_sum<C, Q>), dim3(outc, cur_batch), MSM_TREE, st, (const typename C::XYZZ *)cur, count, nxt);
         typename C::XYZZ *t = cur; cur = nxt; nxt = t;
         count = outc;
     } while (count > 1);
@@ -411,13 +426,14 @@ int MsmWork<C>::launch_reduce(uint32_t K, uint32_t groups, hipStream_t st) {
 
 template <class C>
 int MsmWork<C>::enqueue_reduce(const SortView &v, hipStream_t st, hipStream_t st_tail) {
-    if (!v.sorted || v.nb != sh.nb) return fail_msg(ZK_ERR_ARG, "MSM reduce: the driving sort has a different bucket count");   // a borrowed sort must have this MSM's buckets
-    const uint32_t nb = sh.nb;
-    const uint32_t G0 = sh.group, K = nb < G0 ? nb : G0, groups = nb / K;
+    if (!v.sorted || !v.batch || v.batch > max_batch || v.nb != sh.nb * v.batch) return fail_msg(ZK_ERR_ARG, "MSM reduce: the driving sort has a different bucket count");   // a borrowed sort must have this MSM's buckets
+    cur_batch = v.batch;
+    const uint32_t nb = v.nb;                                   // buckets of all proofs of the batch
+    const uint32_t G0 = sh.group, K = sh.nb < G0 ? sh.nb : G0, groups = sh.nb / K;   // running-sum groups per proof
     ZK_HIP(hipMemsetAsync(heavy_count, 0, sizeof(uint32_t), st));
     // the entry count is only known on the device: launch for the most chunks it can give, threads past the end exit
     const uint64_t max_seg = sh.chunk.max_chunks(v.entries_bound);
-    if (max_seg + nb + 1 > sh.max_pieces()) return fail_msg(ZK_ERR_ARG, "MSM reduce: the driving sort has more entries than this MSM was allocated for");
+    if (max_seg + nb + 1 > sh.chunk.max_chunks(sh.max_entries() * max_batch) + (uint64_t)sh.nb * max_batch + 1) return fail_msg(ZK_ERR_ARG, "MSM reduce: the driving sort has more entries than this MSM was allocated for");
     ZK_HIP(hipEventRecord(ev_acc0, st));
     if (sh.quad_acc == 4)
         ZK_LAUNCH((k_msm_accumulate<C, 4>), zk_div_up(max_seg * 4, 64), 64, st, (const typename C::Affine *)table, v.sorted, v.off,
@@ -432,13 +448,17 @@ int MsmWork<C>::enqueue_reduce(const SortView &v, hipStream_t st, hipStream_t st
     if (rc != ZK_OK) return rc;
     typename C::XYZZ *cur = (tree_levels(groups) & 1) ? partial_b : partial_a;
     ZK_HIP(hipGetLastError());
-    ZK_HIP(hipMemcpyAsync(host_result, cur, sizeof(typename C::XYZZ), hipMemcpyDeviceToHost, st));
+    ZK_HIP(hipMemcpyAsync(host_result, cur, sizeof(typename C::XYZZ) * cur_batch, hipMemcpyDeviceToHost, st));
+    if (dev_result) {
+        if (cur_batch == 1) ZK_HIP(hipMemcpyAsync(dev_result, cur, sizeof(typename C::XYZZ), hipMemcpyDeviceToDevice, st));
+        else ZK_HIP(hipMemcpy2DAsync(dev_result, dev_result_pitch, cur, sizeof(typename C::XYZZ), sizeof(typename C::XYZZ), cur_batch, hipMemcpyDeviceToDevice, st));
+    }
     return ZK_OK;
 }
 
 template <class C>
-int MsmWork<C>::enqueue(const fe *scalars, const uint32_t *gather, uint32_t n, int canonical, hipStream_t st, hipStream_t st_tail) {
-    ZK_TRY(enqueue_sort(scalars, gather, n, canonical, st));
+int MsmWork<C>::enqueue(const fe *scalars, const uint32_t *gather, uint32_t n, int canonical, hipStream_t st, hipStream_t st_tail, uint32_t batch, uint32_t stride) {
+    ZK_TRY(enqueue_sort(scalars, gather, n, canonical, st, batch, stride));
     return enqueue_reduce(view(), st, st_tail);
 }
 

@@ -204,10 +204,13 @@ static ZK_HD bool fr_is_one(const fe &a) {
 }
 static ZK_D fe spmv_term(const fe &coef, const fe &x) { return fr_is_one(coef) ? x : Fr::mul(coef, x); }
 
+// blockIdx.y = proof of a batch: its witness lies w_stride elements, its output out_stride elements further on
 __global__ void k_spmv_rows(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ col,
-                            const fe *__restrict__ coeff, const fe *__restrict__ w, fe *__restrict__ out, uint32_t n_rows) {
+                            const fe *__restrict__ coeff, const fe *__restrict__ w, fe *__restrict__ out, uint32_t n_rows,
+                            uint32_t w_stride, uint32_t out_stride) {
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_rows) return;
+    w += (size_t)blockIdx.y * w_stride; out += (size_t)blockIdx.y * out_stride;
     uint32_t b = row_ptr[j], e = row_ptr[j + 1];
     if (e - b > SPMV_LONG_ROW) return;                     // written by k_spmv_long_finish
     fe acc = Fr::zero();
@@ -219,8 +222,9 @@ __global__ void k_spmv_rows(const uint32_t *__restrict__ row_ptr, const uint32_t
 __global__ void __launch_bounds__(256)
 k_spmv_long_chunks(const uint32_t *__restrict__ chunk_begin, const uint32_t *__restrict__ chunk_end,
                    const uint32_t *__restrict__ col, const fe *__restrict__ coeff, const fe *__restrict__ w,
-                   fe *__restrict__ partial) {
+                   fe *__restrict__ partial, uint32_t w_stride) {
     __shared__ uint32_t sh[8][256];
+    w += (size_t)blockIdx.y * w_stride; partial += (size_t)blockIdx.y * gridDim.x;
     const uint32_t b = chunk_begin[blockIdx.x], e = chunk_end[blockIdx.x];
     fe acc = Fr::zero();
     for (uint32_t k = b + threadIdx.x; k < e; k += blockDim.x) acc = Fr::add(acc, spmv_term(coeff[k], w[col[k]]));
@@ -243,18 +247,19 @@ k_spmv_long_chunks(const uint32_t *__restrict__ chunk_begin, const uint32_t *__r
 
 // thread per long row: sum its chunk partials (chunks of a row are consecutive)
 __global__ void k_spmv_long_finish(const uint32_t *__restrict__ long_row, const uint32_t *__restrict__ long_first_chunk,
-                                   const fe *__restrict__ partial, fe *__restrict__ out, uint32_t n_long) {
+                                   const fe *__restrict__ partial, fe *__restrict__ out, uint32_t n_long, uint32_t n_chunks, uint32_t out_stride) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_long) return;
+    partial += (size_t)blockIdx.y * n_chunks; out += (size_t)blockIdx.y * out_stride;
     fe acc = Fr::zero();
     for (uint32_t k = long_first_chunk[i]; k < long_first_chunk[i + 1]; k++) acc = Fr::add(acc, partial[k]);
     out[long_row[i]] = acc;
 }
 
 // aA[nC + i] = w[i], i = 0..nIn  (input-consistency rows, Appendix A.3 step 1); rest of the pad stays 0
-__global__ void k_set_input_rows(fe *aA, const fe *w, uint32_t nC, uint32_t nIn) {
+__global__ void k_set_input_rows(fe *aA, const fe *w, uint32_t nC, uint32_t nIn, uint32_t w_stride, uint32_t out_stride) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i <= nIn) aA[nC + i] = w[i];
+    if (i <= nIn) aA[(size_t)blockIdx.y * out_stride + nC + i] = w[(size_t)blockIdx.y * w_stride + i];
 }
 
 }  // namespace zk

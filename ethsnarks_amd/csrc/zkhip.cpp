@@ -392,7 +392,7 @@ struct DevCsr {
         for (void *q : p) if (q) hipFree(q);
         *this = DevCsr();
     }
-    int upload(const zk_csr *m, uint32_t V) {
+    int upload(const zk_csr *m, uint32_t V, uint32_t batch) {
         n_rows = m->n_rows;
         nnz = m->row_ptr[n_rows];
         std::vector<uint32_t> lrow, lfirst, cb, ce;
@@ -419,7 +419,7 @@ struct DevCsr {
         ZK_HIP(hipMalloc(&long_first, 4 * (size_t)(n_long + 1)));
         ZK_HIP(hipMalloc(&chunk_begin, 4 * (size_t)(n_chunks + 1)));
         ZK_HIP(hipMalloc(&chunk_end, 4 * (size_t)(n_chunks + 1)));
-        ZK_HIP(hipMalloc(&partial, 32 * (size_t)(n_chunks + 1)));
+        ZK_HIP(hipMalloc(&partial, 32 * ((size_t)n_chunks * batch + 1)));
         if (n_long) ZK_HIP(hipMemcpy(long_row, lrow.data(), 4 * (size_t)n_long, hipMemcpyHostToDevice));
         ZK_HIP(hipMemcpy(long_first, lfirst.data(), 4 * (size_t)(n_long + 1), hipMemcpyHostToDevice));
         if (n_chunks) {
@@ -428,14 +428,14 @@ struct DevCsr {
         }
         return ZK_OK;
     }
-    // out[0..n_rows) = M * w
-    int enqueue(const fe *w, fe *out, hipStream_t st) const {
-        if (n_rows) ZK_LAUNCH(k_spmv_rows, zk_div_up(n_rows, 256), 256, st, (const uint32_t *)row_ptr, (const uint32_t *)col, (const fe *)coeff, w, out, n_rows);
+    // out[p][0..n_rows) = M * w[p] for the `batch` witnesses w_stride elements apart (outputs out_stride apart)
+    int enqueue(const fe *w, fe *out, hipStream_t st, uint32_t batch, uint32_t w_stride, uint32_t out_stride) const {
+        if (n_rows) ZK_LAUNCH(k_spmv_rows, dim3(zk_div_up(n_rows, 256), batch), 256, st, (const uint32_t *)row_ptr, (const uint32_t *)col, (const fe *)coeff, w, out, n_rows, w_stride, out_stride);
         if (n_chunks) {
-            ZK_LAUNCH_SYNC(k_spmv_long_chunks, n_chunks, 256, st, (const uint32_t *)chunk_begin, (const uint32_t *)chunk_end,
-                           (const uint32_t *)col, (const fe *)coeff, w, partial);
-            ZK_LAUNCH(k_spmv_long_finish, zk_div_up(n_long, 64), 64, st, (const uint32_t *)long_row, (const uint32_t *)long_first,
-                      (const fe *)partial, out, n_long);
+            ZK_LAUNCH_SYNC(k_spmv_long_chunks, dim3(n_chunks, batch), 256, st, (const uint32_t *)chunk_begin, (const uint32_t *)chunk_end,
+                           (const uint32_t *)col, (const fe *)coeff, w, partial, w_stride);
+            ZK_LAUNCH(k_spmv_long_finish, dim3(zk_div_up(n_long, 64), batch), 64, st, (const uint32_t *)long_row, (const uint32_t *)long_first,
+                      (const fe *)partial, out, n_long, n_chunks, out_stride);
         }
         ZK_HIP(hipGetLastError());
         return ZK_OK;
@@ -511,6 +511,7 @@ struct zk_ctx {
     DeviceTables *tables = nullptr;
     bool serial = false;
     bool in_flight = false;
+    uint32_t max_batch = 1, cur_batch = 1;     // proofs per launch sequence: capacity, and of the proof(s) in flight
     uint32_t nC = 0, nIn = 0, V = 0, m = 0, logm = 0;
     zk_config cfg{};
     G1::Affine alpha_g1; G2::Affine beta_g2;
@@ -605,20 +606,23 @@ static int ctx_build(zk_ctx *c, const zk_pk *pk, const zk_csr *A, const zk_csr *
     c->dA_idx = c->tables->dA_idx; c->dB_idx = c->tables->dB_idx;
     const DeviceTables *t = c->tables;
     const bool any_share = t->share_A || t->share_B || t->share_L;
-    if (any_share) ZK_TRY(c->mW.alloc(V + 1, t->cW, nullptr, nullptr, /*sort_only=*/true));
-    ZK_TRY(c->mA.alloc(c->rA.n(), c->cfg.multi_exp_c, t->tA, t->share_A ? &c->mW.sh : nullptr));
-    ZK_TRY(c->mH.alloc(c->rH.n(), c->cfg.multi_exp_c, t->tH));
-    ZK_TRY(c->mL.alloc(c->rL.n(), c->cfg.multi_exp_c, t->tL, t->share_L ? &c->mW.sh : nullptr));
-    ZK_TRY(c->mB.alloc(c->rB.n(), c->cfg.multi_exp_c, t->tB, t->share_B ? &c->mW.sh : nullptr));
-    ZK_TRY(c->cA.upload(A, V)); ZK_TRY(c->cB.upload(B, V)); ZK_TRY(c->cC.upload(C, V));
-    ZK_HIP(hipMalloc(&c->d_w, 32 * (size_t)(V + 1)));
-    ZK_HIP(hipMalloc(&c->d_a, 3 * 32 * (size_t)m)); c->d_b = c->d_a + m; c->d_c = c->d_a + 2 * (size_t)m;   // A | B | C: one batched NTT launch per pass
-    ZK_HIP(hipMalloc(&c->d_t, 3 * 32 * (size_t)m));
-    ZK_HIP(hipMalloc(&c->d_partials, sizeof(zk_partials)));
+    const uint32_t KB = c->max_batch;
+    if (any_share) ZK_TRY(c->mW.alloc(V + 1, t->cW, nullptr, nullptr, /*sort_only=*/true, KB));
+    ZK_TRY(c->mA.alloc(c->rA.n(), c->cfg.multi_exp_c, t->tA, t->share_A ? &c->mW.sh : nullptr, false, KB));
+    ZK_TRY(c->mH.alloc(c->rH.n(), c->cfg.multi_exp_c, t->tH, nullptr, false, KB));
+    ZK_TRY(c->mL.alloc(c->rL.n(), c->cfg.multi_exp_c, t->tL, t->share_L ? &c->mW.sh : nullptr, false, KB));
+    ZK_TRY(c->mB.alloc(c->rB.n(), c->cfg.multi_exp_c, t->tB, t->share_B ? &c->mW.sh : nullptr, false, KB));
+    ZK_TRY(c->cA.upload(A, V, KB)); ZK_TRY(c->cB.upload(B, V, KB)); ZK_TRY(c->cC.upload(C, V, KB));
+    ZK_HIP(hipMalloc(&c->d_w, 32 * (size_t)(V + 1) * KB));
+    // A | B | C polynomials of all proofs of a batch: [A: KB x m][B: KB x m][C: KB x m], one batched NTT launch per pass
+    ZK_HIP(hipMalloc(&c->d_a, 3 * 32 * (size_t)m * KB)); c->d_b = c->d_a + (size_t)m * KB; c->d_c = c->d_a + 2 * (size_t)m * KB;
+    ZK_HIP(hipMalloc(&c->d_t, 3 * 32 * (size_t)m * KB));
+    ZK_HIP(hipMalloc(&c->d_partials, sizeof(zk_partials) * KB));
     c->mA.dev_result = (G1::XYZZ *)(c->d_partials + offsetof(zk_partials, At)); c->mB.dev_result = (G2::XYZZ *)(c->d_partials + offsetof(zk_partials, Bt));
     c->mH.dev_result = (G1::XYZZ *)(c->d_partials + offsetof(zk_partials, Ht)); c->mL.dev_result = (G1::XYZZ *)(c->d_partials + offsetof(zk_partials, Lt));
-    ZK_HIP(hipHostMalloc(&c->h_w, 32 * (size_t)(V + 1), hipHostMallocDefault));
-    ZK_HIP(hipHostMalloc(&c->h_tail, 32, hipHostMallocDefault));
+    c->mA.dev_result_pitch = c->mB.dev_result_pitch = c->mH.dev_result_pitch = c->mL.dev_result_pitch = sizeof(zk_partials);
+    ZK_HIP(hipHostMalloc(&c->h_w, 32 * (size_t)(V + 1) * KB, hipHostMallocDefault));
+    ZK_HIP(hipHostMalloc(&c->h_tail, 32 * (size_t)KB, hipHostMallocDefault));
     // s_main carries the critical chain (H polynomial -> H-query): highest priority; the A-, B-, L-query
     // streams fill the machine beside it.  ZK_SERIAL=1 (profiling aid) puts everything on s_main.
     int prio_lo = 0, prio_hi = 0;
@@ -654,6 +658,8 @@ extern "C" int zk_ctx_create(const zk_pk *pk, const zk_csr *A, const zk_csr *B, 
     if (cfg) c->cfg = *cfg;
     if (c->cfg.shard_count > 1 && c->cfg.shard_rank >= c->cfg.shard_count) { delete c; return fail(ZK_ERR_ARG, "shard_rank >= shard_count"); }
     c->device = (int)c->cfg.device;
+    c->max_batch = c->cfg.max_batch ? c->cfg.max_batch : 1;
+    if (c->max_batch > 4096) { delete c; return fail(ZK_ERR_ARG, "max_batch > 4096"); }
     c->nC = nC; c->nIn = nIn; c->V = V; c->m = m;
     while ((1u << c->logm) < m) c->logm++;
     c->alpha_g1 = pk->alpha_g1; c->beta_g2 = pk->beta_g2;
@@ -665,20 +671,23 @@ extern "C" int zk_ctx_create(const zk_pk *pk, const zk_csr *A, const zk_csr *B, 
 extern "C" void zk_ctx_destroy(zk_ctx *ctx) { delete ctx; }
 
 // ---- "Compute the polynomial H" (tcc:460-475) on s_main; result in d_t (natural order), h[m-1] copied to h_tail
+// for the k = cur_batch proofs in flight: polynomials laid out [A: k x m][B: k x m][C: k x m] in d_a, h of proof p at d_t + p m
 static int enqueue_compute_h(zk_ctx *c) {
     hipStream_t st = c->s_main;
-    const uint32_t m = c->m;
-    ZK_HIP(hipMemsetAsync(c->d_a, 0, 3 * 32 * (size_t)m, st));       // d_a | d_b | d_c
-    ZK_TRY(c->cA.enqueue(c->d_w, c->d_a, st));
-    ZK_TRY(c->cB.enqueue(c->d_w, c->d_b, st));
-    ZK_TRY(c->cC.enqueue(c->d_w, c->d_c, st));
-    ZK_LAUNCH(k_set_input_rows, zk_div_up(c->nIn + 1, 64), 64, st, c->d_a, (const fe *)c->d_w, c->nC, c->nIn);
-    // the three polynomials go through each pass together (blockIdx.y): 3 x fewer, 3 x larger launches
-    ZK_TRY(ntt_run(c->tab, c->d_a, c->d_t, true, nullptr, c->tab.inv_then_coset, st, 3, m));   // iFFT, then x g^i (cosetFFT pre-scale)
-    ZK_TRY(ntt_run(c->tab, c->d_t, c->d_a, false, nullptr, nullptr, st, 3, m));               // FFT -> evaluations on the coset
-    ZK_LAUNCH(k_pointwise_h, zk_div_up(m, 256), 256, st, c->d_a, (const fe *)c->d_b, (const fe *)c->d_c, c->tab.zinv, m);
-    ZK_TRY(ntt_run(c->tab, c->d_a, c->d_t, true, nullptr, c->tab.icoset, st));          // icosetFFT
-    ZK_HIP(hipMemcpyAsync(c->h_tail, c->d_t + (m - 1), 32, hipMemcpyDeviceToHost, st));
+    const uint32_t m = c->m, k = c->cur_batch, ws = c->V + 1;
+    fe *a = c->d_a, *b = c->d_a + (size_t)m * k, *cc = c->d_a + 2 * (size_t)m * k;
+    ZK_HIP(hipMemsetAsync(a, 0, 3 * 32 * (size_t)m * k, st));
+    ZK_TRY(c->cA.enqueue(c->d_w, a, st, k, ws, m));
+    ZK_TRY(c->cB.enqueue(c->d_w, b, st, k, ws, m));
+    ZK_TRY(c->cC.enqueue(c->d_w, cc, st, k, ws, m));
+    ZK_LAUNCH(k_set_input_rows, dim3(zk_div_up(c->nIn + 1, 64), k), 64, st, a, (const fe *)c->d_w, c->nC, c->nIn, ws, m);
+    // all 3 k polynomials go through each pass together (blockIdx.y): fewer, larger launches
+    ZK_TRY(ntt_run(c->tab, a, c->d_t, true, nullptr, c->tab.inv_then_coset, st, 3 * k, m));   // iFFT, then x g^i (cosetFFT pre-scale)
+    ZK_TRY(ntt_run(c->tab, c->d_t, a, false, nullptr, nullptr, st, 3 * k, m));               // FFT -> evaluations on the coset
+    ZK_LAUNCH(k_pointwise_h, zk_div_up((uint64_t)m * k, 256), 256, st, a, (const fe *)b, (const fe *)cc, c->tab.zinv, m * k);
+    ZK_TRY(ntt_run(c->tab, a, c->d_t, true, nullptr, c->tab.icoset, st, k, m));          // icosetFFT
+    if (k == 1) ZK_HIP(hipMemcpyAsync(c->h_tail, c->d_t + (m - 1), 32, hipMemcpyDeviceToHost, st));
+    else ZK_HIP(hipMemcpy2DAsync(c->h_tail, 32, c->d_t + (m - 1), 32 * (size_t)m, 32, k, hipMemcpyDeviceToHost, st));
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
@@ -686,11 +695,12 @@ static int enqueue_compute_h(zk_ctx *c) {
 // witness: a host buffer (staged through pinned memory, the reference's pb.values), or -- resident != 0 -- a buffer that
 // already lives in this device's memory (the caller keeps it untouched until the proof is collected)
 static int upload_witness(zk_ctx *c, const uint64_t *witness, int canonical, int resident = 0) {
-    if (!resident) memcpy(c->h_w, witness, 32 * (size_t)(c->V + 1));
+    const size_t n = (size_t)(c->V + 1) * c->cur_batch;          // the witnesses of a batch are contiguous
+    if (!resident) memcpy(c->h_w, witness, 32 * n);
     ZK_HIP(hipEventRecord(c->ev_start, c->s_main));
-    if (resident) ZK_HIP(hipMemcpyAsync(c->d_w, witness, 32 * (size_t)(c->V + 1), hipMemcpyDeviceToDevice, c->s_main));
-    else ZK_HIP(hipMemcpyAsync(c->d_w, c->h_w, 32 * (size_t)(c->V + 1), hipMemcpyHostToDevice, c->s_main));
-    if (canonical) ZK_LAUNCH(k_to_mont, zk_div_up(c->V + 1, 256), 256, c->s_main, c->d_w, c->V + 1);
+    if (resident) ZK_HIP(hipMemcpyAsync(c->d_w, witness, 32 * n, hipMemcpyDeviceToDevice, c->s_main));
+    else ZK_HIP(hipMemcpyAsync(c->d_w, c->h_w, 32 * n, hipMemcpyHostToDevice, c->s_main));
+    if (canonical) ZK_LAUNCH(k_to_mont, zk_div_up(n, 256), 256, c->s_main, c->d_w, (uint32_t)n);
     ZK_HIP(hipEventRecord(c->ev_w, c->s_main));
     return ZK_OK;
 }
@@ -699,10 +709,12 @@ static void store_xyzz(uint64_t *dst, const G1::XYZZ &p) { memcpy(dst, &p, sizeo
 static void store_xyzz(uint64_t *dst, const G2::XYZZ &p) { memcpy(dst, &p, sizeof(p)); }
 
 static int prove_enqueue(zk_ctx *c, const uint64_t *witness, int canonical, int resident);
-static int prove_submit_impl(zk_ctx *c, const uint64_t *witness, int canonical, int resident = 0) {
+static int prove_submit_impl(zk_ctx *c, const uint64_t *witness, int canonical, int resident = 0, uint32_t k = 1) {
     if (!c || !witness) return fail(ZK_ERR_ARG, "null argument");
     if (c->in_flight) return fail(ZK_ERR_ARG, "a proof is already in flight on this context (collect it first)");
+    if (!k || k > c->max_batch) return fail(ZK_ERR_ARG, "batch size exceeds zk_config.max_batch of this context");
     ZK_TRY(use_device(c->device));
+    c->cur_batch = k;
     const int rc = prove_enqueue(c, witness, canonical, resident);
     if (rc != ZK_OK) {      // part of the proof may be queued: drain it so that the next submit cannot overwrite buffers still in use
         hipStreamSynchronize(c->s_main); hipStreamSynchronize(c->s_a); hipStreamSynchronize(c->s_b); hipStreamSynchronize(c->s_l);
@@ -719,23 +731,24 @@ static int prove_enqueue(zk_ctx *c, const uint64_t *witness, int canonical, int 
     // last and keeps its tail on the main stream.
     hipStream_t m = c->s_main;
     const DeviceTables *t = c->tables;
-    if (t->share_A || t->share_B || t->share_L) ZK_TRY(c->mW.enqueue_sort(c->d_w, nullptr, c->V + 1, 0, m));   // one sort of all witness digits
+    const uint32_t k = c->cur_batch, ws = c->V + 1;             // proofs of this launch sequence; witness stride
+    if (t->share_A || t->share_B || t->share_L) ZK_TRY(c->mW.enqueue_sort(c->d_w, nullptr, c->V + 1, 0, m, k, ws));   // one sort of all witness digits
     ZK_HIP(hipEventRecord(c->ev_b0, m));
     if (t->share_B) ZK_TRY(c->mB.enqueue_reduce(c->mW.view_for(0, t->posB), m, c->s_b));         // tcc:499-506
-    else ZK_TRY(c->mB.enqueue(c->d_w, c->dB_idx, c->rB.n(), 0, m, c->s_b));
+    else ZK_TRY(c->mB.enqueue(c->d_w, c->dB_idx, c->rB.n(), 0, m, c->s_b, k, ws));
     ZK_HIP(hipEventRecord(c->ev_b1, c->s_b));
     ZK_HIP(hipEventRecord(c->ev_a0, m));
     if (t->share_A) ZK_TRY(c->mA.enqueue_reduce(c->mW.view_for(0, t->posA), m, c->s_a));         // tcc:488-495
-    else ZK_TRY(c->mA.enqueue(c->d_w, c->dA_idx, c->rA.n(), 0, m, c->s_a));
+    else ZK_TRY(c->mA.enqueue(c->d_w, c->dA_idx, c->rA.n(), 0, m, c->s_a, k, ws));
     ZK_HIP(hipEventRecord(c->ev_a1, c->s_a));
     ZK_HIP(hipEventRecord(c->ev_l0, m));
     if (t->share_L) ZK_TRY(c->mL.enqueue_reduce(c->mW.view_for(c->nIn + 1), m, c->s_l));         // tcc:522-530
-    else ZK_TRY(c->mL.enqueue(c->d_w + (c->nIn + 1) + c->rL.lo, nullptr, c->rL.n(), 0, m, c->s_l));
+    else ZK_TRY(c->mL.enqueue(c->d_w + (c->nIn + 1) + c->rL.lo, nullptr, c->rL.n(), 0, m, c->s_l, k, ws));
     ZK_HIP(hipEventRecord(c->ev_l1, c->s_l));
     ZK_HIP(hipEventRecord(c->ev_h0, m));
     ZK_TRY(enqueue_compute_h(c));
     ZK_HIP(hipEventRecord(c->ev_h, m));
-    ZK_TRY(c->mH.enqueue(c->d_t + c->rH.lo, nullptr, c->rH.n(), 0, m, m));                      // tcc:510-518
+    ZK_TRY(c->mH.enqueue(c->d_t + c->rH.lo, nullptr, c->rH.n(), 0, m, m, k, c->m));              // tcc:510-518
     ZK_HIP(hipEventRecord(c->ev_h1, m));
     return ZK_OK;
 }
@@ -747,11 +760,12 @@ static int prove_collect_impl(zk_ctx *c, zk_partials *out, zk_timings *tm) {    
     c->in_flight = false;
     ZK_HIP(hipStreamSynchronize(c->s_a)); ZK_HIP(hipStreamSynchronize(c->s_b));
     ZK_HIP(hipStreamSynchronize(c->s_l)); ZK_HIP(hipStreamSynchronize(c->s_main));
-    if (!Fr::is_zero(*c->h_tail)) return fail(ZK_ERR_DEGREE, "h[m-1] != 0: the witness does not satisfy the constraint system");
+    for (uint32_t p = 0; p < c->cur_batch; p++)
+        if (!Fr::is_zero(c->h_tail[p])) return fail(ZK_ERR_DEGREE, "h[m-1] != 0: the witness does not satisfy the constraint system");
     double t0 = now_ms();
-    if (out) {
-        store_xyzz(out->At, c->mA.finish()); store_xyzz(out->Bt, c->mB.finish());
-        store_xyzz(out->Ht, c->mH.finish()); store_xyzz(out->Lt, c->mL.finish());
+    if (out) for (uint32_t p = 0; p < c->cur_batch; p++) {      // out: cur_batch records
+        store_xyzz(out[p].At, c->mA.finish(p)); store_xyzz(out[p].Bt, c->mB.finish(p));
+        store_xyzz(out[p].Ht, c->mH.finish(p)); store_xyzz(out[p].Lt, c->mL.finish(p));
     }
     if (tm) {
         memset(tm, 0, sizeof(*tm));
@@ -782,6 +796,23 @@ static int prove_partial_impl(zk_ctx *c, const uint64_t *witness, int canonical,
 // asynchronous form: enqueue a proof and return; collect later (lets two contexts keep the GPU full)
 extern "C" int zk_prove_submit(zk_ctx *ctx, const uint64_t *witness, int canonical) { return prove_submit_impl(ctx, witness, canonical); }
 extern "C" int zk_prove_submit_resident(zk_ctx *ctx, const void *d_witness, int canonical) { return prove_submit_impl(ctx, (const uint64_t *)d_witness, canonical, 1); }
+// ---- several proofs of the circuit through ONE launch sequence: k witnesses, contiguous, k <= zk_config.max_batch
+extern "C" int zk_prove_batch_submit(zk_ctx *ctx, const uint64_t *witnesses, uint32_t k, int canonical) { return prove_submit_impl(ctx, witnesses, canonical, 0, k); }
+extern "C" int zk_prove_batch_submit_resident(zk_ctx *ctx, const void *d_witnesses, uint32_t k, int canonical) { return prove_submit_impl(ctx, (const uint64_t *)d_witnesses, canonical, 1, k); }
+extern "C" int zk_prove_batch_collect(zk_ctx *ctx, zk_partials *out, uint32_t k, zk_timings *t) {
+    if (!ctx || !out) return fail(ZK_ERR_ARG, "null argument");
+    if (ctx->in_flight && k != ctx->cur_batch) return fail(ZK_ERR_ARG, "collect: k differs from the submitted batch size");
+    return prove_collect_impl(ctx, out, t);
+}
+extern "C" int zk_prove_batch(zk_ctx *ctx, const uint64_t *witnesses, uint32_t k, int canonical, zk_proof *out) {
+    if (!ctx || !out) return fail(ZK_ERR_ARG, "null argument");
+    if (ctx->cfg.shard_count > 1) return fail(ZK_ERR_ARG, "sharded context: use zk_prove_batch_submit / _collect + zk_prove_combine per proof");
+    ZK_TRY(prove_submit_impl(ctx, witnesses, canonical, 0, k));
+    std::vector<zk_partials> parts(k);
+    ZK_TRY(prove_collect_impl(ctx, parts.data(), nullptr));
+    for (uint32_t p = 0; p < k; p++) ZK_TRY(zk_prove_combine(ctx, &parts[p], 1, &out[p]));
+    return ZK_OK;
+}
 // what the context chose: {window bits, windows, buckets} of the A-, B-, H-, L-query MSMs, then whether the witness sort is shared
 extern "C" int zk_ctx_info(const zk_ctx *c, uint32_t info[16]) {
     if (!c || !info) return fail(ZK_ERR_ARG, "null argument");
@@ -790,7 +821,11 @@ extern "C" int zk_ctx_info(const zk_ctx *c, uint32_t info[16]) {
     info[12] = c->tables->share_A; info[13] = c->tables->share_B; info[14] = c->tables->share_L; info[15] = c->m;
     return ZK_OK;
 }
-extern "C" int zk_prove_collect(zk_ctx *ctx, zk_partials *out, zk_timings *t) { if (!out) return fail(ZK_ERR_ARG, "null argument"); return prove_collect_impl(ctx, out, t); }
+extern "C" int zk_prove_collect(zk_ctx *ctx, zk_partials *out, zk_timings *t) {
+    if (!ctx || !out) return fail(ZK_ERR_ARG, "null argument");
+    if (ctx->in_flight && ctx->cur_batch != 1) return fail(ZK_ERR_ARG, "a batch is in flight: use zk_prove_batch_collect");
+    return prove_collect_impl(ctx, out, t);
+}
 // device-side exchange of sharded provers: the partial sums stay in a 640-byte device buffer of the context (zk_partials layout,
 // loose Montgomery values), ready for an RCCL all-gather; zk_prove_combine_device takes the gathered device buffer
 extern "C" const void *zk_ctx_partials_device(const zk_ctx *ctx) { return ctx ? ctx->d_partials : nullptr; }
@@ -1077,6 +1112,7 @@ extern "C" int zk_witness_map(zk_ctx *c, const uint64_t *witness, int canonical,
     if (!c || !witness || !h_out) return fail(ZK_ERR_ARG, "null argument");
     if (c->in_flight) return fail(ZK_ERR_ARG, "a proof is in flight on this context (collect it first): its witness and H buffers are in use");
     ZK_TRY(use_device(c->device));
+    c->cur_batch = 1;
     ZK_TRY(upload_witness(c, witness, canonical));
     ZK_TRY(enqueue_compute_h(c));
     ZK_HIP(hipStreamSynchronize(c->s_main));

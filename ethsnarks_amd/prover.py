@@ -33,7 +33,7 @@ class ZkCSR(C.Structure):
 
 class ZkConfig(C.Structure):
     """libsnark::Config (src/prover_config.hpp:8-35) reduced to what a GPU prover consumes."""
-    _fields_ = [("multi_exp_c", C.c_uint32), ("device", C.c_uint32), ("shard_rank", C.c_uint32), ("shard_count", C.c_uint32)]
+    _fields_ = [("multi_exp_c", C.c_uint32), ("device", C.c_uint32), ("shard_rank", C.c_uint32), ("shard_count", C.c_uint32), ("max_batch", C.c_uint32)]
 
 
 class ZkProof(C.Structure):
@@ -60,6 +60,7 @@ EXPORTS = [
     "zk_keygen", "zk_vk_to_json", "zk_vk_from_json", "zk_proof_from_json", "zk_vk_free",
     "zk_domain_size", "zk_ctx_create", "zk_ctx_destroy",
     "zk_prove", "zk_prove_timed", "zk_prove_partial", "zk_prove_partial_timed", "zk_prove_combine", "zk_prove_submit", "zk_prove_collect", "zk_proof_to_json",
+    "zk_prove_batch", "zk_prove_batch_submit", "zk_prove_batch_submit_resident", "zk_prove_batch_collect",
     "zk_prove_submit_resident", "zk_ctx_info", "zk_ctx_partials_device", "zk_prove_collect_device", "zk_prove_combine_device", "zk_launch_count", "zk_profile_begin", "zk_profile_end", "zk_device_info",
     "zk_verify",
     "zk_ntt", "zk_witness_map", "zk_msm_g1", "zk_msm_g2", "zk_field_mul", "zk_fr_convert",
@@ -297,12 +298,13 @@ def get_domain_size(r1cs):
 class ProverContext:
     """ProverContext<ppT> (hpp:279-291) + get_domain: bases and CSR resident in HBM, scratch owned."""
 
-    def __init__(self, pk, r1cs, multi_exp_c=0, device=0, shard_rank=0, shard_count=1):
+    def __init__(self, pk, r1cs, multi_exp_c=0, device=0, shard_rank=0, shard_count=1, max_batch=1):
         lib = load_library(_lib_path_loaded)
         self.r1cs = r1cs
+        self.max_batch = max_batch
         self._keep = []
         a, b, c = _csr_structs(r1cs, self._keep)
-        cfg = ZkConfig(multi_exp_c, device, shard_rank, shard_count)
+        cfg = ZkConfig(multi_exp_c, device, shard_rank, shard_count, max_batch)
         h = C.c_void_p()
         _check(lib.zk_ctx_create(pk._h, C.byref(a), C.byref(b), C.byref(c), C.c_uint32(r1cs.nC), C.c_uint32(r1cs.nIn),
                                  C.c_uint32(r1cs.V), C.byref(cfg), C.byref(h)))
@@ -340,6 +342,34 @@ class ProverContext:
         """enqueue a proof and return (zk_prove_submit); the witness is copied to pinned memory first"""
         w = self._w(witness)
         _check(_lib.zk_prove_submit(self._h, _p64(w), int(canonical)))
+
+    def _wk(self, witnesses):
+        w = _c64(witnesses)
+        per = 4 * (self.r1cs.V + 1)
+        if w.size % per or w.size == 0:
+            raise ValueError("witnesses must be k x (V + 1) elements")
+        return w, w.size // per
+
+    def prove_batch_structs(self, witnesses, canonical=False):
+        """zk_prove_batch: k witnesses of this circuit through one launch sequence -> list of k ZkProof"""
+        w, k = self._wk(witnesses)
+        proofs = (ZkProof * k)()
+        _check(_lib.zk_prove_batch(self._h, _p64(w), C.c_uint32(k), int(canonical), proofs))
+        return list(proofs)
+
+    def submit_batch(self, witnesses, canonical=False, device_ptr=None, k=None):
+        if device_ptr is not None:
+            _check(_lib.zk_prove_batch_submit_resident(self._h, C.c_void_p(device_ptr), C.c_uint32(k), int(canonical)))
+            return k
+        w, k = self._wk(witnesses)
+        _check(_lib.zk_prove_batch_submit(self._h, _p64(w), C.c_uint32(k), int(canonical)))
+        return k
+
+    def collect_batch(self, k):
+        """(partials[k, 80 u64], timings)"""
+        parts, t = (ZkPartials * k)(), ZkTimings()
+        _check(_lib.zk_prove_batch_collect(self._h, parts, C.c_uint32(k), C.byref(t)))
+        return np.frombuffer(bytes(parts), dtype=np.uint64).reshape(k, 80).copy(), t.as_dict()
 
     def submit_resident(self, device_ptr, canonical=False):
         """zk_prove_submit_resident: the witness already lives in this device's memory (device_ptr = integer address of
@@ -411,6 +441,13 @@ def proof_to_json(proof, inputs, canonical=False):
     ln = C.c_size_t(0)
     _check(_lib.zk_proof_to_json(C.byref(proof), _p64(inputs) if n else None, C.c_uint32(n), int(canonical), buf, C.c_size_t(cap), C.byref(ln)))
     return buf.raw[:ln.value].decode()
+
+
+def prove_batch(ctx, witnesses, canonical=False):
+    """k proofs of one circuit in one launch sequence (zk_prove_batch): list of proof JSON strings, each byte-identical to
+    prove(ctx, witness_p)"""
+    w = _c64(witnesses).reshape(-1, ctx.r1cs.V + 1, 4)
+    return [proof_to_json(p, w[i, 1:1 + ctx.r1cs.nIn], canonical) for i, p in enumerate(ctx.prove_batch_structs(w, canonical))]
 
 
 def prove(ctx, witness, canonical=False):

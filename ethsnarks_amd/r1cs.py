@@ -146,14 +146,18 @@ def synthetic_chain(nC, nIn=1, seed=SEED_DEFAULT):
     return R1CS(nC, nIn, V, mk(a_ptr, a_col), mk(b_ptr, b_col), mk(c_ptr, c_col)), w
 
 
-def random_r1cs(nC, nIn, n_extra_vars=3, max_terms=4, seed=1, small_values=False):
+def random_r1cs(nC, nIn, n_extra_vars=3, max_terms=4, seed=1, small_values=False, witness_seed=None):
     """Random satisfiable R1CS with general coefficients (parity-test material):
     row j: <A_j, x> * <B_j, x> = k_j * x_new; some rows are zero rows; `n_extra_vars` variables are
     never referenced (their L-query entries are the point at infinity, A/B entries absent).
-    small_values: witness seeds drawn from {0, 1, 2, 3} to exercise the 0/1 scalar partitions."""
+    small_values: witness seeds drawn from {0, 1, 2, 3} to exercise the 0/1 scalar partitions.
+    witness_seed: the same constraint system (it depends on `seed` alone) with another satisfying witness."""
     rng = SplitMix64(seed)
+    wrng = SplitMix64(witness_seed) if witness_seed is not None else None
     n_free = nIn + 2
     w = [1] + [(rng.next() % 4 if small_values else rng.fr()) for _ in range(n_free)]
+    if wrng is not None:
+        w = [1] + [(wrng.next() % 4 if small_values else wrng.fr()) for _ in range(n_free)]
     A, B, C = [], [], []
     for j in range(nC):
         if j % 7 == 5:                       # zero row: 0 * 0 = 0
@@ -168,7 +172,8 @@ def random_r1cs(nC, nIn, n_extra_vars=3, max_terms=4, seed=1, small_values=False
         w.append(val)
         A.append(ra); B.append(rb); C.append([(nv, k)])
     for _ in range(n_extra_vars):
-        w.append(rng.fr())
+        v = rng.fr()
+        w.append(wrng.fr() if wrng is not None else v)
     V = len(w) - 1
     return R1CS(nC, nIn, V, CSR.from_rows(A), CSR.from_rows(B), CSR.from_rows(C)), w
 

@@ -73,6 +73,7 @@ typedef struct {
     uint32_t device;           /* HIP device ordinal */
     uint32_t shard_rank;       /* MSM base-range sharding: this context owns shard_rank of shard_count */
     uint32_t shard_count;      /* 0 or 1 = unsharded */
+    uint32_t max_batch;        /* proofs of this circuit one launch sequence may carry (zk_prove_batch); 0 or 1 = one at a time */
 } zk_config;
 
 /* canonical (non-Montgomery) affine coordinates; *_inf != 0 => point at infinity, printed as (0, 1) */
@@ -169,6 +170,15 @@ int zk_prove_collect(zk_ctx *ctx, zk_partials *out, zk_timings *t);
 const void *zk_ctx_partials_device(const zk_ctx *ctx);
 int zk_prove_collect_device(zk_ctx *ctx, zk_timings *t);
 int zk_prove_combine_device(const zk_ctx *ctx, const void *d_parts, uint32_t count, zk_proof *out);
+/* ---- several proofs of ONE circuit per launch sequence (the reference's nearest idea is the scratch reuse of
+ * ProverContext, hpp:286-289): k <= zk_config.max_batch witnesses, contiguous (k x (V + 1) x 4 u64).  The k digit streams are
+ * bucket-sorted together under the key (proof, bucket) and every kernel of the prover runs once for all of them, which is what
+ * small circuits need: one proof alone is ~50 launches of latency-bound kernels.  Proof p is byte-identical to zk_prove of
+ * witness p.  out: k records. */
+int zk_prove_batch(zk_ctx *ctx, const uint64_t *witnesses, uint32_t k, int canonical, zk_proof *out);
+int zk_prove_batch_submit(zk_ctx *ctx, const uint64_t *witnesses, uint32_t k, int canonical);
+int zk_prove_batch_submit_resident(zk_ctx *ctx, const void *d_witnesses, uint32_t k, int canonical);
+int zk_prove_batch_collect(zk_ctx *ctx, zk_partials *out, uint32_t k, zk_timings *t);
 /* zk_prove_submit for a witness that is already resident in the context's device memory (d_witness = device
  * pointer to (V + 1) x 32 bytes, e.g. written by a GPU witness generator); it must stay untouched until collected */
 int zk_prove_submit_resident(zk_ctx *ctx, const void *d_witness, int canonical);

@@ -172,3 +172,47 @@ def test_no_public_inputs_and_tiny_domain(zk, oracle):
         assert got == expect
         assert zk.stub_verify(vk_o.to_json(), got)
         assert pyref.verify(json.loads(vk_o.to_json()), json.loads(got))
+
+
+@pytest.mark.parametrize("k", [1, 3, 4])
+def test_prove_batch_equals_independent_proofs(zk, oracle, k):
+    """zk_prove_batch: k witnesses of one circuit through one launch sequence (sort key (proof, bucket)); proof p must be
+    byte-identical to the oracle's proof of witness p.  k = 3: a batch that is not a power of two (partly filled last
+    coarse bin of the sort).  Sparse B / A queries and unreferenced variables: the non-shared-sort and gather paths."""
+    r, _ = R.random_r1cs(40, 2, n_extra_vars=3, seed=31)
+    pk_o, _ = oracle.keygen(r, seed=8)
+    pk = zk.ProvingKey.from_parts(**pk_o.parts())
+    ws, expect = [], []
+    for p in range(k):
+        r_p, w = R.random_r1cs(40, 2, n_extra_vars=3, seed=31, witness_seed=(100 + p) if p else None)
+        assert np.array_equal(r_p.A.col, r.A.col) and np.array_equal(r_p.C.coeff, r.C.coeff)      # same constraint system
+        wm = F.fr_to_mont(w)
+        ws.append(wm); expect.append(oracle.prove(pk_o, r, wm)[0])
+    ctx = zk.ProverContext(pk, r, max_batch=4)
+    assert zk.prove_batch(ctx, np.stack(ws)) == expect
+    assert zk.prove(ctx, ws[-1]) == expect[-1]                       # the same context still proves one at a time
+    if k > 1:
+        with pytest.raises(zk.ZkError):
+            zk.prove_batch(ctx, np.stack(ws * 3))                    # 3k > max_batch
+        bad = [w.copy() for w in ws]
+        bad[1] = F.fr_to_mont([(int(v) + (i == len(bad[1]) - 4)) % F.FR for i, v in enumerate(F.fr_from_mont(bad[1]))])
+        with pytest.raises(zk.ZkError) as e:
+            zk.prove_batch(ctx, np.stack(bad))                       # one unsatisfied witness fails the batch (degree check)
+        assert e.value.code == 7
+    ctx.close()
+
+
+def test_prove_batch_chain_shared_sort(zk, oracle):
+    """dense queries (the chain circuit): the A-, B- and L-query ride ONE shared sort of the k witness digit streams"""
+    r, w0 = R.synthetic_chain(254, 1)
+    pk_o, _ = oracle.keygen(r, seed=4)
+    pk = zk.ProvingKey.from_parts(**pk_o.parts())
+    ws = [F.fr_to_mont(R.synthetic_chain(254, 1, seed=500 + p)[1]) for p in range(3)]
+    expect = [oracle.prove(pk_o, r, w)[0] for w in ws]
+    ctx = zk.ProverContext(pk, r, max_batch=3)
+    assert ctx.info()["share_B"]
+    assert zk.prove_batch(ctx, np.stack(ws)) == expect
+    k = ctx.submit_batch(np.stack(ws[:2]))                            # asynchronous form, a smaller batch than the capacity
+    parts, _ = ctx.collect_batch(k)
+    assert [zk.proof_to_json(ctx.prove_combine(parts[p]), ws[p][1:2]) for p in range(2)] == expect[:2]
+    ctx.close()

@@ -241,6 +241,45 @@ def test_config4_merkle_membership_depth29(hip, oracle):
     assert hip.prove(ctx, F.fr_to_mont(w2)) == expect2
 
 
+@pytest.mark.parametrize("k", [1, 4, 16])
+def test_prove_batch_merkle29(hip, oracle, k):
+    """k membership proofs of the depth-29 MiMC Merkle circuit (different leaves, addresses and paths: many
+    0/1-valued witness entries) through ONE launch sequence; proof p is byte-identical to the oracle's proof of witness p"""
+    from ethsnarks_amd import gadgets as G
+    r, w0, _ = G.merkle_membership_circuit(29)
+    pk, vk = hip.keygen(r, seed=29)
+    pk_o = oracle.pk_from_parts(pk.parts())
+    ws = [F.fr_to_mont(w0)]
+    for p in range(1, k):
+        _, w, _ = G.merkle_membership_circuit(29, leaf=1000 + p, address=(0x15555555 * (p + 1)) & ((1 << 29) - 1), path=[G.merkle_unique(d, 7 + p) for d in range(29)])
+        ws.append(F.fr_to_mont(w))
+    expect = [oracle.prove(pk_o, r, w)[0] for w in ws]
+    ctx = hip.ProverContext(pk, r, max_batch=16)
+    got = hip.prove_batch(ctx, np.stack(ws))
+    assert got == expect
+    assert all(hip.stub_verify(vk.to_json(), g) for g in got[:2])
+    assert hip.prove(ctx, ws[-1]) == expect[-1]                    # single proofs on the same context
+    ctx.close()
+
+
+def test_prove_batch_chain_shared_sort_and_odd_batch(hip, oracle):
+    """dense queries (A-, B-, L-query on one shared witness sort), a batch that is not a power of two, the asynchronous form"""
+    r, _ = R.synthetic_chain((1 << 12) - 2, 1)
+    pk_o, _ = oracle.keygen(r, seed=12)
+    pk = hip.ProvingKey.from_parts(**pk_o.parts())
+    ws = [F.fr_to_mont(R.synthetic_chain((1 << 12) - 2, 1, seed=700 + p)[1]) for p in range(5)]
+    expect = [oracle.prove(pk_o, r, w)[0] for w in ws]
+    ctx = hip.ProverContext(pk, r, max_batch=8)
+    assert ctx.info()["share_B"]
+    assert hip.prove_batch(ctx, np.stack(ws)) == expect
+    k = ctx.submit_batch(np.stack(ws[1:4]))
+    parts, _ = ctx.collect_batch(k)
+    assert [hip.proof_to_json(ctx.prove_combine(parts[p]), ws[1 + p][1:2]) for p in range(3)] == expect[1:4]
+    with pytest.raises(hip.ZkError):
+        hip.prove_batch(ctx, np.stack(ws * 2))                      # 10 > max_batch
+    ctx.close()
+
+
 def test_config2_chain_2pow18_gpu_keygen(hip, oracle, tmp_path):
     """BASELINE config 2: synthetic chain, 2^18 constraints, real key from zk_keygen via the .raw file,
     proof bit-exact vs the CPU oracle on the same key"""
