@@ -474,7 +474,10 @@ struct DeviceTables {
     // holds at least 7/8 of the variables (absent entries are skipped lane-locally); sparser queries and sharded
     // contexts sort their own scalars
     bool share_A = false, share_B = false, share_L = false;
-    uint32_t *posA = nullptr, *posB = nullptr;         // witness index -> query entry (0xffffffff: the query has none)
+    uint32_t win_lo = 0, win_n = 0;                    // the witness window [win_lo, win_lo + win_n) the shared sort covers: all V + 1 variables
+                                                       // when unsharded, the span of this shard's A / B / L entries otherwise
+    uint32_t *posA = nullptr, *posB = nullptr;         // window position -> entry of this shard's query (0xffffffff: none); nullptr: position - offX
+    uint32_t offA = 0, offB = 0, offL = 0;
     uint32_t cW = 0;                                   // window bits of the shared witness sort and of the tables it drives
     int refs = 0;
 };
@@ -569,25 +572,40 @@ static int ctx_build(zk_ctx *c, const zk_pk *pk, const zk_csr *A, const zk_csr *
             t = new (std::nothrow) DeviceTables();
             if (!t) return ZK_ERR_NOMEM;
             t->pk_id = pk->id; t->device = c->device; t->rank = r; t->count = G; t->cbits = c->cfg.multi_exp_c;
-            const uint64_t dense = ((uint64_t)V + 1) * 7 / 8;
-            const bool can_share = G == 1 && V + 1 >= 64 && !getenv("ZK_NO_SHARED_SORT");
-            t->share_A = can_share && pk->a_val.size() >= dense;
-            t->share_B = can_share && pk->b_val.size() >= dense;
-            t->share_L = can_share && (uint64_t)(V - nIn) >= dense;
+            // The A-, B- and L-query all read the witness: ONE bucket sort of the witness digits drives every query that is
+            // dense in the window it covers.  Unsharded the window is the whole witness; a shard's window is the span of the
+            // witness indices its three base ranges touch (base-range sharding cuts the three queries at about the same place).
+            uint32_t lo = 0xffffffffu, hi = 0;
+            auto span = [&](uint32_t first, uint32_t last) { if (first < lo) lo = first; if (last + 1 > hi) hi = last + 1; };
+            if (c->rA.n()) span(pk->a_idx[c->rA.lo], pk->a_idx[c->rA.hi - 1]);
+            if (c->rB.n()) span(pk->b_idx[c->rB.lo], pk->b_idx[c->rB.hi - 1]);
+            if (c->rL.n()) span(nIn + 1 + c->rL.lo, nIn + c->rL.hi);
+            if (G == 1) { lo = 0; hi = V + 1; }
+            if (lo > hi) lo = hi = 0;
+            t->win_lo = lo; t->win_n = hi - lo;
+            const uint64_t dense = (uint64_t)t->win_n * 7 / 8;
+            const bool can_share = t->win_n >= 64 && !getenv("ZK_NO_SHARED_SORT");
+            t->share_A = can_share && c->rA.n() >= dense;
+            t->share_B = can_share && c->rB.n() >= dense;
+            t->share_L = can_share && c->rL.n() >= dense;
             if ((int)t->share_A + (int)t->share_B + (int)t->share_L < 2) t->share_A = t->share_B = t->share_L = false;   // nothing to share
-            t->cW = t->cbits ? t->cbits : MsmShape::pick_c(V + 1);
+            t->cW = t->cbits ? t->cbits : MsmShape::pick_c(t->win_n ? t->win_n : 1);
             int rc = dev_upload(&t->dA_idx, pk->a_idx.data() + c->rA.lo, c->rA.n());
             if (rc == ZK_OK) rc = dev_upload(&t->dB_idx, pk->b_idx.data() + c->rB.lo, c->rB.n());
-            auto inverse = [&](const std::vector<uint32_t> &idx, uint32_t **out) -> int {
-                bool prefix = true;                                  // entries 0..n-1 in place: index == position, no map needed
-                for (size_t k = 0; k < idx.size() && prefix; k++) prefix = idx[k] == k;
-                if (prefix) { *out = nullptr; return ZK_OK; }
-                std::vector<uint32_t> pos((size_t)V + 1, 0xffffffffu);
-                for (size_t k = 0; k < idx.size(); k++) pos[idx[k]] = (uint32_t)k;
+            // window position -> shard entry: consecutive indices need no map (entry = position - off), else an explicit one
+            auto inverse = [&](const std::vector<uint32_t> &idx, Range r, uint32_t **out, uint32_t *off) -> int {
+                *out = nullptr; *off = 0;
+                if (!r.n()) return ZK_OK;
+                bool run = true;
+                for (uint32_t k = r.lo; k < r.hi && run; k++) run = idx[k] == idx[r.lo] + (k - r.lo);
+                if (run) { *off = idx[r.lo] - t->win_lo; return ZK_OK; }
+                std::vector<uint32_t> pos(t->win_n, 0xffffffffu);
+                for (uint32_t k = r.lo; k < r.hi; k++) pos[idx[k] - t->win_lo] = k - r.lo;
                 return dev_upload(out, pos.data(), pos.size());
             };
-            if (rc == ZK_OK && t->share_A) rc = inverse(pk->a_idx, &t->posA);
-            if (rc == ZK_OK && t->share_B) rc = inverse(pk->b_idx, &t->posB);
+            if (rc == ZK_OK && t->share_A) rc = inverse(pk->a_idx, c->rA, &t->posA, &t->offA);
+            if (rc == ZK_OK && t->share_B) rc = inverse(pk->b_idx, c->rB, &t->posB, &t->offB);
+            t->offL = c->rL.n() ? nIn + 1 + c->rL.lo - t->win_lo : 0;
             if (rc == ZK_OK) rc = build_table<G1>(&t->tA, pk->a_val.data() + c->rA.lo, c->rA.n(), t->share_A ? t->cW : t->cbits);
             if (rc == ZK_OK) rc = build_table<G1>(&t->tH, pk->H.data() + c->rH.lo, c->rH.n(), t->cbits);
             if (rc == ZK_OK) rc = build_table<G1>(&t->tL, pk->L.data() + c->rL.lo, c->rL.n(), t->share_L ? t->cW : t->cbits);
@@ -607,7 +625,7 @@ static int ctx_build(zk_ctx *c, const zk_pk *pk, const zk_csr *A, const zk_csr *
     const DeviceTables *t = c->tables;
     const bool any_share = t->share_A || t->share_B || t->share_L;
     const uint32_t KB = c->max_batch;
-    if (any_share) ZK_TRY(c->mW.alloc(V + 1, t->cW, nullptr, nullptr, /*sort_only=*/true, KB));
+    if (any_share) ZK_TRY(c->mW.alloc(t->win_n, t->cW, nullptr, nullptr, /*sort_only=*/true, KB));
     ZK_TRY(c->mA.alloc(c->rA.n(), c->cfg.multi_exp_c, t->tA, t->share_A ? &c->mW.sh : nullptr, false, KB));
     ZK_TRY(c->mH.alloc(c->rH.n(), c->cfg.multi_exp_c, t->tH, nullptr, false, KB));
     ZK_TRY(c->mL.alloc(c->rL.n(), c->cfg.multi_exp_c, t->tL, t->share_L ? &c->mW.sh : nullptr, false, KB));
@@ -732,17 +750,17 @@ static int prove_enqueue(zk_ctx *c, const uint64_t *witness, int canonical, int 
     hipStream_t m = c->s_main;
     const DeviceTables *t = c->tables;
     const uint32_t k = c->cur_batch, ws = c->V + 1;             // proofs of this launch sequence; witness stride
-    if (t->share_A || t->share_B || t->share_L) ZK_TRY(c->mW.enqueue_sort(c->d_w, nullptr, c->V + 1, 0, m, k, ws));   // one sort of all witness digits
+    if (t->share_A || t->share_B || t->share_L) ZK_TRY(c->mW.enqueue_sort(c->d_w + t->win_lo, nullptr, t->win_n, 0, m, k, ws));   // one sort of the witness digits of the window
     ZK_HIP(hipEventRecord(c->ev_b0, m));
-    if (t->share_B) ZK_TRY(c->mB.enqueue_reduce(c->mW.view_for(0, t->posB), m, c->s_b));         // tcc:499-506
+    if (t->share_B) ZK_TRY(c->mB.enqueue_reduce(c->mW.view_for(t->offB, t->posB), m, c->s_b));   // tcc:499-506
     else ZK_TRY(c->mB.enqueue(c->d_w, c->dB_idx, c->rB.n(), 0, m, c->s_b, k, ws));
     ZK_HIP(hipEventRecord(c->ev_b1, c->s_b));
     ZK_HIP(hipEventRecord(c->ev_a0, m));
-    if (t->share_A) ZK_TRY(c->mA.enqueue_reduce(c->mW.view_for(0, t->posA), m, c->s_a));         // tcc:488-495
+    if (t->share_A) ZK_TRY(c->mA.enqueue_reduce(c->mW.view_for(t->offA, t->posA), m, c->s_a));   // tcc:488-495
     else ZK_TRY(c->mA.enqueue(c->d_w, c->dA_idx, c->rA.n(), 0, m, c->s_a, k, ws));
     ZK_HIP(hipEventRecord(c->ev_a1, c->s_a));
     ZK_HIP(hipEventRecord(c->ev_l0, m));
-    if (t->share_L) ZK_TRY(c->mL.enqueue_reduce(c->mW.view_for(c->nIn + 1), m, c->s_l));         // tcc:522-530
+    if (t->share_L) ZK_TRY(c->mL.enqueue_reduce(c->mW.view_for(t->offL), m, c->s_l));           // tcc:522-530
     else ZK_TRY(c->mL.enqueue(c->d_w + (c->nIn + 1) + c->rL.lo, nullptr, c->rL.n(), 0, m, c->s_l, k, ws));
     ZK_HIP(hipEventRecord(c->ev_l1, c->s_l));
     ZK_HIP(hipEventRecord(c->ev_h0, m));

@@ -1,5 +1,6 @@
-"""N > 1 path on CPU: world_size-2 gloo ranks, each with a sharded prover context (CPU emulation build of
-the HIP sources), exchange their 640-byte partials with all_gather and must reproduce the oracle's proof."""
+"""N > 1 path on CPU: world_size-2 and -4 gloo ranks, each with a sharded prover context (CPU emulation build of
+the HIP sources, shipped launch shapes), exchange their 640-byte partials with all_gather -- through the same
+device-buffer entry points the GPU path uses -- and must reproduce the oracle's proof."""
 import os
 import socket
 import sys
@@ -24,22 +25,23 @@ def _worker(rank, world, port, emul_so, q):
     from ethsnarks_amd import prover as P, r1cs as R, fields as F
     from ethsnarks_amd.sharded import ShardedProver
     P.load_library(emul_so)
-    r, w = R.synthetic_chain(126, 1)
+    r, w = R.synthetic_chain(510, 1)
     wm = F.fr_to_mont(w)
     pk_o, _ = O.keygen(r, seed=17)
     expect, _ = O.prove(pk_o, r, wm)
     pk = P.ProvingKey.from_parts(**pk_o.parts())
     ctx = P.ProverContext(pk, r, shard_rank=rank, shard_count=world)
+    shared = ctx.info()["share_B"]                      # the rank's A / B / L shards ride one shared witness sort
     sp = ShardedProver(ctx, dist, torch.device("cpu"))
     got = P.proof_to_json(sp.prove_struct(wm), wm[1:2])
     got2 = P.proof_to_json(sp.prove_struct(wm, timings=True)[0], wm[1:2])
-    q.put((rank, got == expect and got2 == expect))
+    q.put((rank, got == expect and got2 == expect and shared))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_sharded_prove_two_ranks_gloo(emul):
-    world = 2
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_prove_gloo(emul, world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -49,4 +51,4 @@ def test_sharded_prove_two_ranks_gloo(emul):
     results = [q.get(timeout=300) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
-    assert sorted(results) == [(0, True), (1, True)]
+    assert sorted(results) == [(k, True) for k in range(world)]
