@@ -9,12 +9,14 @@ def short(n):
     return m.group(1) if m else n[:40]
 ev = [(int(r['Start_Timestamp']), int(r['End_Timestamp']), short(r['Kernel_Name']), int(r['Queue_Id'])) for r in rows]
 ev.sort()
-# steady-state window: from the first k_msm_accumulate after the last k_msm_precompute to the last event
-t_pre = max([e[1] for e in ev if 'precompute' in e[2]] or [ev[0][0]])
-win = [e for e in ev if e[0] >= t_pre]
-skip = float(sys.argv[2]) if len(sys.argv) > 2 else 0.3
-t0 = win[0][0] + int((win[-1][1] - win[0][0]) * skip); t1 = win[-1][1]
-win = [e for e in win if e[0] >= t0]
+# steady-state window: G2 accumulations number FIRST .. LAST of the run (argv[2], argv[3]; default 8 .. 22: inside the timed
+# steps of `bench.py --steps 20 --warmup 5`), start of the first to start of the last
+g2 = [e for e in ev if e[2].startswith('k_msm_accumulate<G2')]
+first = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+last = int(sys.argv[3]) if len(sys.argv) > 3 else 22
+t0, t1 = g2[first][0], g2[last][0]
+print("%d proofs in %.2f ms: %.3f ms per proof" % (last - first, (t1 - t0) / 1e6, (t1 - t0) / 1e6 / (last - first)))
+win = [e for e in ev if e[0] >= t0 and e[0] < t1]
 span = (t1 - t0) / 1e6
 print("window %.2f ms, %d dispatches" % (span, len(win)))
 def union(iv):
