@@ -92,7 +92,7 @@ def main():
         torch.cuda.set_device(0)
     gloo = rehearse and world > 1
 
-    P.load_library()                                   # raises if libzkhip.so is missing: no CPU fallback
+    P.load_library(os.environ.get("ZK_LIB") or None)  # raises if libzkhip.so is missing: no CPU fallback (ZK_LIB: A/B of two builds of the library)
     devinfo = P.device_info(local_rank)
 
     def make_workload(workload, logm):
