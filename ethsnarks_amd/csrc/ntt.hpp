@@ -65,11 +65,10 @@ k_ntt_pass(const fe *__restrict__ in, fe *__restrict__ out, const fe *__restrict
             uint32_t jm = q & (half - 1), grp = q >> (s - 1);
             uint32_t eu = (((grp << s) | jm) << logc) | c, ev = eu + (half << logc);
             uint32_t j = (jm << s0) | ((lb << logc) | c);      // index inside the half-group of stage S
-            fe w = tw[(size_t)j << (logm - S)];
             fe u, v;
 #pragma unroll
             for (int l = 0; l < 8; l++) { u.l[l] = sh[l][eu]; v.l[l] = sh[l][ev]; }
-            v = Fr::mul(v, w);
+            if (S > 1) v = Fr::mul(v, tw[(size_t)j << (logm - S)]);   // stage 1: every twiddle is w^0 = 1 (uniform branch)
             fe a = Fr::add(u, v), b = Fr::sub(u, v);
 #pragma unroll
             for (int l = 0; l < 8; l++) { sh[l][eu] = a.l[l]; sh[l][ev] = b.l[l]; }

@@ -636,8 +636,10 @@ static int ctx_build(zk_ctx *c, const zk_pk *pk, const zk_csr *A, const zk_csr *
     ZK_HIP(hipMalloc(&c->d_a, 3 * 32 * (size_t)m * KB)); c->d_b = c->d_a + (size_t)m * KB; c->d_c = c->d_a + 2 * (size_t)m * KB;
     ZK_HIP(hipMalloc(&c->d_t, 3 * 32 * (size_t)m * KB));
     ZK_HIP(hipMalloc(&c->d_partials, sizeof(zk_partials) * KB));
-    c->mA.dev_result = (G1::XYZZ *)(c->d_partials + offsetof(zk_partials, At)); c->mB.dev_result = (G2::XYZZ *)(c->d_partials + offsetof(zk_partials, Bt));
-    c->mH.dev_result = (G1::XYZZ *)(c->d_partials + offsetof(zk_partials, Ht)); c->mL.dev_result = (G1::XYZZ *)(c->d_partials + offsetof(zk_partials, Lt));
+    if (G > 1) {      // sharded provers exchange the device copy of their partial sums (zk_prove_collect_device)
+        c->mA.dev_result = (G1::XYZZ *)(c->d_partials + offsetof(zk_partials, At)); c->mB.dev_result = (G2::XYZZ *)(c->d_partials + offsetof(zk_partials, Bt));
+        c->mH.dev_result = (G1::XYZZ *)(c->d_partials + offsetof(zk_partials, Ht)); c->mL.dev_result = (G1::XYZZ *)(c->d_partials + offsetof(zk_partials, Lt));
+    }
     c->mA.dev_result_pitch = c->mB.dev_result_pitch = c->mH.dev_result_pitch = c->mL.dev_result_pitch = sizeof(zk_partials);
     ZK_HIP(hipHostMalloc(&c->h_w, 32 * (size_t)(V + 1) * KB, hipHostMallocDefault));
     ZK_HIP(hipHostMalloc(&c->h_tail, 32 * (size_t)KB, hipHostMallocDefault));
@@ -694,7 +696,9 @@ static int enqueue_compute_h(zk_ctx *c) {
     hipStream_t st = c->s_main;
     const uint32_t m = c->m, k = c->cur_batch, ws = c->V + 1;
     fe *a = c->d_a, *b = c->d_a + (size_t)m * k, *cc = c->d_a + 2 * (size_t)m * k;
-    ZK_HIP(hipMemsetAsync(a, 0, 3 * 32 * (size_t)m * k, st));
+    // rows [nC, m) of every polynomial are padding (the input-consistency rows of A are set below): only they need zeroing,
+    // the row evaluations write every row below nC
+    if (m > c->nC) ZK_HIP(hipMemset2DAsync(a + c->nC, 32 * (size_t)m, 0, 32 * (size_t)(m - c->nC), 3 * (size_t)k, st));
     ZK_TRY(c->cA.enqueue(c->d_w, a, st, k, ws, m));
     ZK_TRY(c->cB.enqueue(c->d_w, b, st, k, ws, m));
     ZK_TRY(c->cC.enqueue(c->d_w, cc, st, k, ws, m));
@@ -847,7 +851,10 @@ extern "C" int zk_prove_collect(zk_ctx *ctx, zk_partials *out, zk_timings *t) {
 // device-side exchange of sharded provers: the partial sums stay in a 640-byte device buffer of the context (zk_partials layout,
 // loose Montgomery values), ready for an RCCL all-gather; zk_prove_combine_device takes the gathered device buffer
 extern "C" const void *zk_ctx_partials_device(const zk_ctx *ctx) { return ctx ? ctx->d_partials : nullptr; }
-extern "C" int zk_prove_collect_device(zk_ctx *ctx, zk_timings *t) { return prove_collect_impl(ctx, nullptr, t); }
+extern "C" int zk_prove_collect_device(zk_ctx *ctx, zk_timings *t) {
+    if (ctx && ctx->cfg.shard_count <= 1) return fail(ZK_ERR_ARG, "zk_prove_collect_device: only sharded contexts keep a device copy of their partial sums");
+    return prove_collect_impl(ctx, nullptr, t);
+}
 
 template <class F> static void canon4(uint64_t dst[4], const fe &mont) { fe c = F::from_mont(mont); memcpy(dst, c.l, 32); }
 static void put_g1(const G1::XYZZ &p, uint64_t x[4], uint64_t y[4], uint32_t *inf) {

@@ -25,7 +25,7 @@ def _worker(rank, world, port, emul_so, q):
     from ethsnarks_amd import prover as P, r1cs as R, fields as F
     from ethsnarks_amd.sharded import ShardedProver
     P.load_library(emul_so)
-    r, w = R.synthetic_chain(510, 1)
+    r, w = R.synthetic_chain(254, 1)
     wm = F.fr_to_mont(w)
     pk_o, _ = O.keygen(r, seed=17)
     expect, _ = O.prove(pk_o, r, wm)

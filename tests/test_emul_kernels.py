@@ -96,7 +96,7 @@ def test_prove_golden(zk, oracle, case):
 
 
 def test_prove_chain_long_rows_and_sharding(zk, oracle, tmp_path):
-    r, w = R.synthetic_chain(510, 1)                    # last row: 1022 terms -> long-row path
+    r, w = R.synthetic_chain(254, 1)                    # last row: 510 terms -> long-row path
     wm = F.fr_to_mont(w)
     pk_o, _ = oracle.keygen(r, seed=3)
     expect, _ = oracle.prove(pk_o, r, wm)
