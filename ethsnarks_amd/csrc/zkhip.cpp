@@ -528,7 +528,8 @@ struct zk_ctx {
     fe *h_tail = nullptr;                      // pinned: h[m-1] for the degree check
     NttTables tab;
     MsmWork<G1> mA, mH, mL, mW; MsmWork<G2> mB;       // mW: sort-only, the shared witness-digit sort
-    hipStream_t s_main = nullptr, s_a = nullptr, s_b = nullptr, s_l = nullptr;
+    hipStream_t s_main = nullptr, s_acc = nullptr, s_a = nullptr, s_b = nullptr, s_l = nullptr;
+    hipEvent_t ev_sort = nullptr;              // a finished bucket sort on s_main releases its accumulation on s_acc
     hipEvent_t ev_start = nullptr, ev_w = nullptr, ev_h = nullptr, ev_a0 = nullptr, ev_a1 = nullptr, ev_b0 = nullptr, ev_b1 = nullptr,
                ev_l0 = nullptr, ev_l1 = nullptr, ev_h1 = nullptr, ev_h0 = nullptr;
     ~zk_ctx() {
@@ -542,7 +543,9 @@ struct zk_ctx {
         mA.release(); mH.release(); mL.release(); mB.release(); mW.release();
         tables_release(tables);
         if (serial) s_a = s_b = s_l = nullptr;
-        hipStream_t ss[] = {s_main, s_a, s_b, s_l};
+        if (s_acc == s_main) s_acc = nullptr;
+        if (ev_sort) hipEventDestroy(ev_sort);
+        hipStream_t ss[] = {s_main, s_acc, s_a, s_b, s_l};
         for (auto s : ss) if (s) hipStreamDestroy(s);
         hipEvent_t ee[] = {ev_start, ev_w, ev_h, ev_a0, ev_a1, ev_b0, ev_b1, ev_l0, ev_l1, ev_h1, ev_h0};
         for (auto e : ee) if (e) hipEventDestroy(e);
@@ -643,18 +646,32 @@ static int ctx_build(zk_ctx *c, const zk_pk *pk, const zk_csr *A, const zk_csr *
     c->mA.dev_result_pitch = c->mB.dev_result_pitch = c->mH.dev_result_pitch = c->mL.dev_result_pitch = sizeof(zk_partials);
     ZK_HIP(hipHostMalloc(&c->h_w, 32 * (size_t)(V + 1) * KB, hipHostMallocDefault));
     ZK_HIP(hipHostMalloc(&c->h_tail, 32 * (size_t)KB, hipHostMallocDefault));
-    // s_main carries the critical chain (H polynomial -> H-query): highest priority; the A-, B-, L-query
-    // streams fill the machine beside it.  ZK_SERIAL=1 (profiling aid) puts everything on s_main.
+    // s_main (high priority) carries the short memory- and latency-bound kernels: witness upload, bucket sorts, the H
+    // polynomial pipeline; s_acc (low priority) carries the four machine-filling accumulation kernels, each released by
+    // the event of its sort; the bucket-reduction tails run on side streams.  The priorities make the dispatcher hand freed
+    // wave slots to the short kernels first, so the H pipeline advances in the shadow of the A-, B-, L-accumulations of the
+    // same proof instead of queueing behind them.  ZK_SERIAL=1 (profiling aid) puts everything on s_main;
+    // ZK_SPLIT_STREAMS=0 keeps the accumulations on s_main as well (the round-1 schedule).
     int prio_lo = 0, prio_hi = 0;
     ZK_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-    ZK_HIP(hipStreamCreateWithPriority(&c->s_main, hipStreamNonBlocking, prio_hi));
+    // stream priorities, in the order main, accumulate, A-tail, B-tail, L-tail: h(igh) / n(ormal) / l(ow).  Measured at 2^20 with
+    // three proofs in flight (profiles/r02_stream_priorities.txt): the accumulations and the A- / L-tails low, the rest high is
+    // the best of the combinations tried; every tail high costs 12 % (their few, register-heavy waves push accumulation waves out).
+    const char *pr = getenv("ZK_PRIOS");                              // tuning aid
+    if (!pr || strlen(pr) != 5) pr = "hllhl";
+    auto prio = [&](char ch) { return ch == 'h' ? prio_hi : ch == 'l' ? prio_lo : (prio_hi + prio_lo) / 2; };
+    ZK_HIP(hipStreamCreateWithPriority(&c->s_main, hipStreamNonBlocking, prio(pr[0])));
     const char *serial = getenv("ZK_SERIAL");
     c->serial = serial && serial[0] == '1';
+    const char *split = getenv("ZK_SPLIT_STREAMS");
+    if (c->serial || (split && split[0] == '0')) c->s_acc = c->s_main;
+    else ZK_HIP(hipStreamCreateWithPriority(&c->s_acc, hipStreamNonBlocking, prio(pr[1])));
+    ZK_HIP(hipEventCreate(&c->ev_sort));
     if (c->serial) { c->s_a = c->s_b = c->s_l = c->s_main; }
     else {
-        ZK_HIP(hipStreamCreateWithPriority(&c->s_a, hipStreamNonBlocking, prio_lo));
-        ZK_HIP(hipStreamCreateWithPriority(&c->s_b, hipStreamNonBlocking, prio_hi));
-        ZK_HIP(hipStreamCreateWithPriority(&c->s_l, hipStreamNonBlocking, prio_lo));
+        ZK_HIP(hipStreamCreateWithPriority(&c->s_a, hipStreamNonBlocking, prio(pr[2])));
+        ZK_HIP(hipStreamCreateWithPriority(&c->s_b, hipStreamNonBlocking, prio(pr[3])));
+        ZK_HIP(hipStreamCreateWithPriority(&c->s_l, hipStreamNonBlocking, prio(pr[4])));
     }
     hipEvent_t *ee[] = {&c->ev_start, &c->ev_w, &c->ev_h, &c->ev_a0, &c->ev_a1, &c->ev_b0, &c->ev_b1, &c->ev_l0, &c->ev_l1, &c->ev_h1, &c->ev_h0};
     for (auto e : ee) ZK_HIP(hipEventCreate(e));
@@ -739,7 +756,7 @@ static int prove_submit_impl(zk_ctx *c, const uint64_t *witness, int canonical, 
     c->cur_batch = k;
     const int rc = prove_enqueue(c, witness, canonical, resident);
     if (rc != ZK_OK) {      // part of the proof may be queued: drain it so that the next submit cannot overwrite buffers still in use
-        hipStreamSynchronize(c->s_main); hipStreamSynchronize(c->s_a); hipStreamSynchronize(c->s_b); hipStreamSynchronize(c->s_l);
+        hipStreamSynchronize(c->s_main); hipStreamSynchronize(c->s_acc); hipStreamSynchronize(c->s_a); hipStreamSynchronize(c->s_b); hipStreamSynchronize(c->s_l);
         return rc;
     }
     c->in_flight = true;
@@ -747,30 +764,34 @@ static int prove_submit_impl(zk_ctx *c, const uint64_t *witness, int canonical, 
 }
 static int prove_enqueue(zk_ctx *c, const uint64_t *witness, int canonical, int resident) {
     ZK_TRY(upload_witness(c, witness, canonical, resident));
-    // One in-order stream carries every machine-filling kernel (sorts, accumulations, the H pipeline) so that
-    // none of them is stretched by contention; the low-parallelism bucket reductions ("tails") of the B-, A-
-    // and L-query run on side streams beside the next accumulation.  Longest tail (G2) first; the H-query is
-    // last and keeps its tail on the main stream.
-    hipStream_t m = c->s_main;
+    // sorts and the H pipeline on m (high priority), accumulations on q (low priority), tails on side streams; longest tail
+    // (G2) first.  A sort that finishes on m releases its accumulation on q through ev_sort.
+    hipStream_t m = c->s_main, q = c->s_acc;
     const DeviceTables *t = c->tables;
     const uint32_t k = c->cur_batch, ws = c->V + 1;             // proofs of this launch sequence; witness stride
-    if (t->share_A || t->share_B || t->share_L) ZK_TRY(c->mW.enqueue_sort(c->d_w + t->win_lo, nullptr, t->win_n, 0, m, k, ws));   // one sort of the witness digits of the window
-    ZK_HIP(hipEventRecord(c->ev_b0, m));
-    if (t->share_B) ZK_TRY(c->mB.enqueue_reduce(c->mW.view_for(t->offB, t->posB), m, c->s_b));   // tcc:499-506
-    else ZK_TRY(c->mB.enqueue(c->d_w, c->dB_idx, c->rB.n(), 0, m, c->s_b, k, ws));
+    auto release = [&]() -> int { if (q != m) { ZK_HIP(hipEventRecord(c->ev_sort, m)); ZK_HIP(hipStreamWaitEvent(q, c->ev_sort, 0)); } return ZK_OK; };
+    if (t->share_A || t->share_B || t->share_L) {               // one sort of the witness digits of the window
+        ZK_TRY(c->mW.enqueue_sort(c->d_w + t->win_lo, nullptr, t->win_n, 0, m, k, ws));
+        ZK_TRY(release());
+    }
+    if (!t->share_B) { ZK_TRY(c->mB.enqueue_sort(c->d_w, c->dB_idx, c->rB.n(), 0, m, k, ws)); ZK_TRY(release()); }
+    ZK_HIP(hipEventRecord(c->ev_b0, q));
+    ZK_TRY(c->mB.enqueue_reduce(t->share_B ? c->mW.view_for(t->offB, t->posB) : c->mB.view(), q, c->s_b));    // tcc:499-506
     ZK_HIP(hipEventRecord(c->ev_b1, c->s_b));
-    ZK_HIP(hipEventRecord(c->ev_a0, m));
-    if (t->share_A) ZK_TRY(c->mA.enqueue_reduce(c->mW.view_for(t->offA, t->posA), m, c->s_a));   // tcc:488-495
-    else ZK_TRY(c->mA.enqueue(c->d_w, c->dA_idx, c->rA.n(), 0, m, c->s_a, k, ws));
+    if (!t->share_A) { ZK_TRY(c->mA.enqueue_sort(c->d_w, c->dA_idx, c->rA.n(), 0, m, k, ws)); ZK_TRY(release()); }
+    ZK_HIP(hipEventRecord(c->ev_a0, q));
+    ZK_TRY(c->mA.enqueue_reduce(t->share_A ? c->mW.view_for(t->offA, t->posA) : c->mA.view(), q, c->s_a));    // tcc:488-495
     ZK_HIP(hipEventRecord(c->ev_a1, c->s_a));
-    ZK_HIP(hipEventRecord(c->ev_l0, m));
-    if (t->share_L) ZK_TRY(c->mL.enqueue_reduce(c->mW.view_for(t->offL), m, c->s_l));           // tcc:522-530
-    else ZK_TRY(c->mL.enqueue(c->d_w + (c->nIn + 1) + c->rL.lo, nullptr, c->rL.n(), 0, m, c->s_l, k, ws));
+    if (!t->share_L) { ZK_TRY(c->mL.enqueue_sort(c->d_w + (c->nIn + 1) + c->rL.lo, nullptr, c->rL.n(), 0, m, k, ws)); ZK_TRY(release()); }
+    ZK_HIP(hipEventRecord(c->ev_l0, q));
+    ZK_TRY(c->mL.enqueue_reduce(t->share_L ? c->mW.view_for(t->offL) : c->mL.view(), q, c->s_l));            // tcc:522-530
     ZK_HIP(hipEventRecord(c->ev_l1, c->s_l));
     ZK_HIP(hipEventRecord(c->ev_h0, m));
     ZK_TRY(enqueue_compute_h(c));
     ZK_HIP(hipEventRecord(c->ev_h, m));
-    ZK_TRY(c->mH.enqueue(c->d_t + c->rH.lo, nullptr, c->rH.n(), 0, m, m, k, c->m));              // tcc:510-518
+    ZK_TRY(c->mH.enqueue_sort(c->d_t + c->rH.lo, nullptr, c->rH.n(), 0, m, k, c->m));             // tcc:510-518
+    ZK_TRY(release());
+    ZK_TRY(c->mH.enqueue_reduce(c->mH.view(), q, m));
     ZK_HIP(hipEventRecord(c->ev_h1, m));
     return ZK_OK;
 }
@@ -780,7 +801,7 @@ static int prove_collect_impl(zk_ctx *c, zk_partials *out, zk_timings *tm) {    
     if (!c->in_flight) return fail(ZK_ERR_ARG, "no proof in flight on this context");
     ZK_TRY(use_device(c->device));
     c->in_flight = false;
-    ZK_HIP(hipStreamSynchronize(c->s_a)); ZK_HIP(hipStreamSynchronize(c->s_b));
+    ZK_HIP(hipStreamSynchronize(c->s_acc)); ZK_HIP(hipStreamSynchronize(c->s_a)); ZK_HIP(hipStreamSynchronize(c->s_b));
     ZK_HIP(hipStreamSynchronize(c->s_l)); ZK_HIP(hipStreamSynchronize(c->s_main));
     for (uint32_t p = 0; p < c->cur_batch; p++)
         if (!Fr::is_zero(c->h_tail[p])) return fail(ZK_ERR_DEGREE, "h[m-1] != 0: the witness does not satisfy the constraint system");
