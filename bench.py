@@ -230,6 +230,22 @@ def main():
                                          "matches_replica_proof": s2["json"] == js}
             except Exception as e:                              # the headline line must survive a failure of an extra leg
                 extras["msm_sharded"] = {"error": repr(e)[:300]}
+            if world >= 3:                                      # SURVEY 8(e) option 2: A / B / C transform chains on three ranks, one proof at a time
+                try:
+                    ctx2 = P.ProverContext(pk, r1cs, multi_exp_c=args.multi_exp_c, device=local_rank, shard_rank=rank, shard_count=world)
+                    sp2 = ShardedProver(ctx2, dist, "cpu" if gloo else torch.device("cuda", local_rank))
+                    lat = {}
+                    for name, fn in (("split_witness_map", sp2.prove_struct_split_witness_map), ("replicated_witness_map", sp2.prove_struct)):
+                        fn(wm); sync()
+                        t0 = time.perf_counter()
+                        for _ in range(short):
+                            pr = fn(wm)
+                        sync()
+                        lat[name] = {"ms_per_proof": round(1e3 * (time.perf_counter() - t0) / short, 3), "matches_replica_proof": P.proof_to_json(pr, wm[1:1 + r1cs.nIn]) == js}
+                    extras["msm_sharded_latency"] = dict(lat, note="one sharded proof at a time (no pipelining): witness map replicated on every rank vs its A / B / C chains on ranks 0-2 (SURVEY 8(e) option 2)")
+                    ctx2.close()
+                except Exception as e:
+                    extras["msm_sharded_latency"] = {"error": repr(e)[:300]}
             if args.workload == "chain" and args.shard_logm and args.shard_logm != logm:
                 try:
                     r5, w5, pk5, name5, _, _ = make_workload("chain", args.shard_logm)

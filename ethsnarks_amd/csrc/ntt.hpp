@@ -95,11 +95,11 @@ __global__ void k_fill_geometric(fe *out, uint32_t n, fe g, fe s) {
     for (uint32_t i = i0; i < end; i++) { out[i] = t; t = Fr::mul(t, g); }
 }
 
-// H on the coset: a[i] = (a[i] * b[i] - c[i]) * zinv     (divide_by_Z_on_coset fused)
-__global__ void k_pointwise_h(fe *a, const fe *b, const fe *c, fe zinv, uint32_t m) {
+// H on the coset: out[i] = (a[i] * b[i] - c[i]) * zinv     (divide_by_Z_on_coset fused); out may be a
+__global__ void k_pointwise_h(fe *out, const fe *a, const fe *b, const fe *c, fe zinv, uint32_t m) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
-    a[i] = Fr::mul(Fr::sub(Fr::mul(a[i], b[i]), c[i]), zinv);
+    out[i] = Fr::mul(Fr::sub(Fr::mul(a[i], b[i]), c[i]), zinv);
 }
 
 struct NttTables {

@@ -723,11 +723,37 @@ static int enqueue_compute_h(zk_ctx *c) {
     // all 3 k polynomials go through each pass together (blockIdx.y): fewer, larger launches
     ZK_TRY(ntt_run(c->tab, a, c->d_t, true, nullptr, c->tab.inv_then_coset, st, 3 * k, m));   // iFFT, then x g^i (cosetFFT pre-scale)
     ZK_TRY(ntt_run(c->tab, c->d_t, a, false, nullptr, nullptr, st, 3 * k, m));               // FFT -> evaluations on the coset
-    ZK_LAUNCH(k_pointwise_h, zk_div_up((uint64_t)m * k, 256), 256, st, a, (const fe *)b, (const fe *)cc, c->tab.zinv, m * k);
+    ZK_LAUNCH(k_pointwise_h, zk_div_up((uint64_t)m * k, 256), 256, st, a, (const fe *)a, (const fe *)b, (const fe *)cc, c->tab.zinv, m * k);
     ZK_TRY(ntt_run(c->tab, a, c->d_t, true, nullptr, c->tab.icoset, st, k, m));          // icosetFFT
     if (k == 1) ZK_HIP(hipMemcpyAsync(c->h_tail, c->d_t + (m - 1), 32, hipMemcpyDeviceToHost, st));
     else ZK_HIP(hipMemcpy2DAsync(c->h_tail, 32, c->d_t + (m - 1), 32 * (size_t)m, 32, k, hipMemcpyDeviceToHost, st));
     ZK_HIP(hipGetLastError());
+    return ZK_OK;
+}
+
+// ---- SURVEY 8(e) option 2 (sharded latency mode): the A, B and C transform chains of the witness map on three different
+// ranks.  One chain = row evaluations of one matrix, iFFT, cosetFFT; its m coset evaluations stay in d_a + which * m.
+static int enqueue_chain(zk_ctx *c, int which) {
+    hipStream_t st = c->s_main;
+    const uint32_t m = c->m, ws = c->V + 1;
+    fe *p = c->d_a + (size_t)which * m, *tmp = c->d_t + (size_t)which * m;
+    if (m > c->nC) ZK_HIP(hipMemsetAsync(p + c->nC, 0, 32 * (size_t)(m - c->nC), st));
+    const DevCsr &M = which == 0 ? c->cA : which == 1 ? c->cB : c->cC;
+    ZK_TRY(M.enqueue(c->d_w, p, st, 1, ws, m));
+    if (which == 0) ZK_LAUNCH(k_set_input_rows, dim3(zk_div_up(c->nIn + 1, 64), 1), 64, st, p, (const fe *)c->d_w, c->nC, c->nIn, ws, m);
+    ZK_TRY(ntt_run(c->tab, p, tmp, true, nullptr, c->tab.inv_then_coset, st));
+    ZK_TRY(ntt_run(c->tab, tmp, p, false, nullptr, nullptr, st));
+    return ZK_OK;
+}
+// h from the three chains (device pointers, m elements each; they may live anywhere in this device's memory): result in d_t
+static int enqueue_h_from_chains(zk_ctx *c, const fe *a, const fe *b, const fe *cc) {
+    hipStream_t st = c->s_main;
+    const uint32_t m = c->m;
+    fe *tmp = c->d_a + 3 * (size_t)m * c->max_batch - m;           // the last m elements of the polynomial buffer: free when batch = 1
+    if (c->max_batch == 1) tmp = c->d_t + m;                        // (d_t holds 3 m elements; h goes to its first m)
+    ZK_LAUNCH(k_pointwise_h, zk_div_up(m, 256), 256, st, tmp, a, b, cc, c->tab.zinv, m);
+    ZK_TRY(ntt_run(c->tab, tmp, c->d_t, true, nullptr, c->tab.icoset, st));
+    ZK_HIP(hipMemcpyAsync(c->h_tail, c->d_t + (m - 1), 32, hipMemcpyDeviceToHost, st));
     return ZK_OK;
 }
 
@@ -747,14 +773,14 @@ static int upload_witness(zk_ctx *c, const uint64_t *witness, int canonical, int
 static void store_xyzz(uint64_t *dst, const G1::XYZZ &p) { memcpy(dst, &p, sizeof(p)); }
 static void store_xyzz(uint64_t *dst, const G2::XYZZ &p) { memcpy(dst, &p, sizeof(p)); }
 
-static int prove_enqueue(zk_ctx *c, const uint64_t *witness, int canonical, int resident);
-static int prove_submit_impl(zk_ctx *c, const uint64_t *witness, int canonical, int resident = 0, uint32_t k = 1) {
+static int prove_enqueue(zk_ctx *c, const uint64_t *witness, int canonical, int resident, const fe *d_h);
+static int prove_submit_impl(zk_ctx *c, const uint64_t *witness, int canonical, int resident = 0, uint32_t k = 1, const fe *d_h = nullptr) {
     if (!c || !witness) return fail(ZK_ERR_ARG, "null argument");
     if (c->in_flight) return fail(ZK_ERR_ARG, "a proof is already in flight on this context (collect it first)");
     if (!k || k > c->max_batch) return fail(ZK_ERR_ARG, "batch size exceeds zk_config.max_batch of this context");
     ZK_TRY(use_device(c->device));
     c->cur_batch = k;
-    const int rc = prove_enqueue(c, witness, canonical, resident);
+    const int rc = prove_enqueue(c, witness, canonical, resident, d_h);
     if (rc != ZK_OK) {      // part of the proof may be queued: drain it so that the next submit cannot overwrite buffers still in use
         hipStreamSynchronize(c->s_main); hipStreamSynchronize(c->s_acc); hipStreamSynchronize(c->s_a); hipStreamSynchronize(c->s_b); hipStreamSynchronize(c->s_l);
         return rc;
@@ -762,7 +788,8 @@ static int prove_submit_impl(zk_ctx *c, const uint64_t *witness, int canonical, 
     c->in_flight = true;
     return ZK_OK;
 }
-static int prove_enqueue(zk_ctx *c, const uint64_t *witness, int canonical, int resident) {
+// d_h != nullptr: the H polynomial was computed elsewhere (option 2); this shard's coefficients [rH.lo, rH.hi) lie at d_h
+static int prove_enqueue(zk_ctx *c, const uint64_t *witness, int canonical, int resident, const fe *d_h) {
     ZK_TRY(upload_witness(c, witness, canonical, resident));
     // sorts and the H pipeline on m (high priority), accumulations on q (low priority), tails on side streams; longest tail
     // (G2) first.  A sort that finishes on m releases its accumulation on q through ev_sort.
@@ -787,9 +814,10 @@ static int prove_enqueue(zk_ctx *c, const uint64_t *witness, int canonical, int 
     ZK_TRY(c->mL.enqueue_reduce(t->share_L ? c->mW.view_for(t->offL) : c->mL.view(), q, c->s_l));            // tcc:522-530
     ZK_HIP(hipEventRecord(c->ev_l1, c->s_l));
     ZK_HIP(hipEventRecord(c->ev_h0, m));
-    ZK_TRY(enqueue_compute_h(c));
+    if (!d_h) ZK_TRY(enqueue_compute_h(c));
+    else memset(c->h_tail, 0, 32);                              // the rank that computed h has checked its degree
     ZK_HIP(hipEventRecord(c->ev_h, m));
-    ZK_TRY(c->mH.enqueue_sort(c->d_t + c->rH.lo, nullptr, c->rH.n(), 0, m, k, c->m));             // tcc:510-518
+    ZK_TRY(c->mH.enqueue_sort(d_h ? d_h : c->d_t + c->rH.lo, nullptr, c->rH.n(), 0, m, k, c->m));   // tcc:510-518
     ZK_TRY(release());
     ZK_TRY(c->mH.enqueue_reduce(c->mH.view(), q, m));
     ZK_HIP(hipEventRecord(c->ev_h1, m));
@@ -839,6 +867,36 @@ static int prove_partial_impl(zk_ctx *c, const uint64_t *witness, int canonical,
 // asynchronous form: enqueue a proof and return; collect later (lets two contexts keep the GPU full)
 extern "C" int zk_prove_submit(zk_ctx *ctx, const uint64_t *witness, int canonical) { return prove_submit_impl(ctx, witness, canonical); }
 extern "C" int zk_prove_submit_resident(zk_ctx *ctx, const void *d_witness, int canonical) { return prove_submit_impl(ctx, (const uint64_t *)d_witness, canonical, 1); }
+// ---- SURVEY 8(e) option 2: the transform chains of the witness map on different ranks (ethsnarks_amd/sharded.py drives it)
+extern "C" int zk_chain_submit(zk_ctx *c, const uint64_t *witness, int canonical, int which) {
+    if (!c || !witness || which < 0 || which > 2) return fail(ZK_ERR_ARG, "bad argument");
+    if (c->in_flight) return fail(ZK_ERR_ARG, "a proof is in flight on this context (collect it first)");
+    ZK_TRY(use_device(c->device));
+    c->cur_batch = 1;
+    ZK_TRY(upload_witness(c, witness, canonical));
+    return enqueue_chain(c, which);
+}
+extern "C" const void *zk_chain_device(const zk_ctx *c, int which) { return (c && which >= 0 && which <= 2) ? c->d_a + (size_t)which * c->m : nullptr; }
+extern "C" int zk_h_from_chains_submit(zk_ctx *c, const void *dA, const void *dB, const void *dC) {
+    if (!c || !dA || !dB || !dC) return fail(ZK_ERR_ARG, "null argument");
+    if (c->in_flight) return fail(ZK_ERR_ARG, "a proof is in flight on this context (collect it first)");
+    ZK_TRY(use_device(c->device));
+    return enqueue_h_from_chains(c, (const fe *)dA, (const fe *)dB, (const fe *)dC);
+}
+extern "C" const void *zk_h_device(const zk_ctx *c) { return c ? c->d_t : nullptr; }
+// waits for the chain / h work queued so far; after zk_h_from_chains_submit it also checks the degree of h
+extern "C" int zk_chain_wait(zk_ctx *c, int check_degree) {
+    if (!c) return fail(ZK_ERR_ARG, "null argument");
+    ZK_TRY(use_device(c->device));
+    ZK_HIP(hipStreamSynchronize(c->s_main));
+    if (check_degree && !Fr::is_zero(c->h_tail[0])) return fail(ZK_ERR_DEGREE, "h[m-1] != 0: the witness does not satisfy the constraint system");
+    return ZK_OK;
+}
+extern "C" int zk_prove_submit_with_h(zk_ctx *c, const uint64_t *witness, int canonical, const void *d_h) {
+    if (!d_h) return fail(ZK_ERR_ARG, "null argument");
+    return prove_submit_impl(c, witness, canonical, 0, 1, (const fe *)d_h);
+}
+
 // ---- several proofs of the circuit through ONE launch sequence: k witnesses, contiguous, k <= zk_config.max_batch
 extern "C" int zk_prove_batch_submit(zk_ctx *ctx, const uint64_t *witnesses, uint32_t k, int canonical) { return prove_submit_impl(ctx, witnesses, canonical, 0, k); }
 extern "C" int zk_prove_batch_submit_resident(zk_ctx *ctx, const void *d_witnesses, uint32_t k, int canonical) { return prove_submit_impl(ctx, (const uint64_t *)d_witnesses, canonical, 1, k); }

@@ -61,6 +61,7 @@ EXPORTS = [
     "zk_domain_size", "zk_ctx_create", "zk_ctx_destroy",
     "zk_prove", "zk_prove_timed", "zk_prove_partial", "zk_prove_partial_timed", "zk_prove_combine", "zk_prove_submit", "zk_prove_collect", "zk_proof_to_json",
     "zk_prove_batch", "zk_prove_batch_submit", "zk_prove_batch_submit_resident", "zk_prove_batch_collect",
+    "zk_chain_submit", "zk_chain_device", "zk_h_from_chains_submit", "zk_h_device", "zk_chain_wait", "zk_prove_submit_with_h",
     "zk_prove_submit_resident", "zk_ctx_info", "zk_ctx_partials_device", "zk_prove_collect_device", "zk_prove_combine_device", "zk_launch_count", "zk_profile_begin", "zk_profile_end", "zk_device_info",
     "zk_verify",
     "zk_ntt", "zk_witness_map", "zk_msm_g1", "zk_msm_g2", "zk_field_mul", "zk_fr_convert",
@@ -86,6 +87,8 @@ def load_library(path=None):
     L.zk_domain_size.restype = C.c_uint32
     L.zk_launch_count.restype = C.c_uint64
     L.zk_ctx_partials_device.restype = C.c_void_p
+    L.zk_chain_device.restype = C.c_void_p
+    L.zk_h_device.restype = C.c_void_p
     _lib, _lib_path_loaded = L, path
     return L
 
@@ -390,6 +393,25 @@ class ProverContext:
         part, t = ZkPartials(), ZkTimings()
         _check(_lib.zk_prove_collect(self._h, C.byref(part), C.byref(t)))
         return np.frombuffer(bytes(part), dtype=np.uint64).copy(), t.as_dict()
+
+    # SURVEY 8(e) option 2 building blocks (ethsnarks_amd/sharded.py drives them)
+    def chain_submit(self, witness, which, canonical=False):
+        _check(_lib.zk_chain_submit(self._h, _p64(self._w(witness)), int(canonical), int(which)))
+
+    def chain_device_ptr(self, which):
+        return int(_lib.zk_chain_device(self._h, int(which)))
+
+    def h_from_chains_submit(self, pa, pb, pc):
+        _check(_lib.zk_h_from_chains_submit(self._h, C.c_void_p(pa), C.c_void_p(pb), C.c_void_p(pc)))
+
+    def h_device_ptr(self):
+        return int(_lib.zk_h_device(self._h))
+
+    def chain_wait(self, check_degree=False):
+        _check(_lib.zk_chain_wait(self._h, int(check_degree)))
+
+    def submit_with_h(self, witness, h_device_ptr, canonical=False):
+        _check(_lib.zk_prove_submit_with_h(self._h, _p64(self._w(witness)), int(canonical), C.c_void_p(h_device_ptr)))
 
     def partials_device_ptr(self):
         """address of the context's 640-byte device copy of the partial sums (valid after collect_device)"""

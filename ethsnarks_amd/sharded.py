@@ -48,6 +48,52 @@ class ShardedProver:
             torch.cuda.current_stream(self.device).synchronize()
         return self.ctx.prove_combine_device(self.buf.data_ptr(), self.world), tm
 
+    def _view(self, ptr, nbytes):
+        if self.device.type == "cuda":
+            return torch.as_tensor(_DevView(ptr, nbytes), device=self.device)
+        return torch.from_numpy(np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(ptr)))
+
+    def prove_struct_split_witness_map(self, witness, canonical=False):
+        """SURVEY 8(e) option 2: instead of every rank recomputing the whole witness map, ranks 0, 1, 2 run the A, B and C
+        transform chains (row evaluations, iFFT, cosetFFT), ranks 1 and 2 send their m coset evaluations to rank 0 (two
+        32 m-byte peer transfers), rank 0 forms H ((a b - c) / Z, icosetFFT: 3 transforms on the critical path instead of 7)
+        and sends every rank the coefficients its H-query shard multiplies.  Needs at least three ranks."""
+        ctx, dist, rank, world = self.ctx, self.dist, self.dist.get_rank(), self.world
+        if world < 3:
+            return self.prove_struct(witness, canonical)
+        m = ctx.r1cs.domain_size
+        shard = lambda r: ((m - 1) * r // world, (m - 1) * (r + 1) // world)      # zk_ctx_create's base-range rule for H
+        if rank < 3:
+            ctx.chain_submit(witness, rank, canonical)
+            ctx.chain_wait()
+        if rank == 0:
+            got = [torch.empty(32 * m, dtype=torch.uint8, device=self.device) for _ in range(2)]
+            reqs = [dist.irecv(got[i], src=i + 1) for i in range(2)]
+            for q in reqs:
+                q.wait()
+            if self.device.type == "cuda":
+                torch.cuda.current_stream(self.device).synchronize()
+            ctx.h_from_chains_submit(ctx.chain_device_ptr(0), got[0].data_ptr(), got[1].data_ptr())
+            ctx.chain_wait(check_degree=True)
+            h = self._view(ctx.h_device_ptr(), 32 * m)
+            reqs = [dist.isend(h[32 * shard(r)[0]:32 * shard(r)[1]], dst=r) for r in range(1, world)]
+            lo, hi = shard(0)
+            ctx.submit_with_h(witness, ctx.h_device_ptr() + 32 * lo, canonical)
+            for q in reqs:
+                q.wait()
+        else:
+            if rank < 3:
+                dist.send(self._view(ctx.chain_device_ptr(rank), 32 * m), dst=0)
+            lo, hi = shard(rank)
+            mine_h = torch.empty(32 * (hi - lo), dtype=torch.uint8, device=self.device)
+            dist.recv(mine_h, src=0)
+            if self.device.type == "cuda":
+                torch.cuda.current_stream(self.device).synchronize()
+            self._keep_h = mine_h                                       # stays alive until the proof is collected
+            ctx.submit_with_h(witness, mine_h.data_ptr(), canonical)
+        proof, _ = self.finish()
+        return proof
+
     def prove_struct(self, witness, canonical=False, timings=False):
         self.submit(witness, canonical)
         proof, tm = self.finish()

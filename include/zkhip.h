@@ -179,6 +179,20 @@ int zk_prove_batch(zk_ctx *ctx, const uint64_t *witnesses, uint32_t k, int canon
 int zk_prove_batch_submit(zk_ctx *ctx, const uint64_t *witnesses, uint32_t k, int canonical);
 int zk_prove_batch_submit_resident(zk_ctx *ctx, const void *d_witnesses, uint32_t k, int canonical);
 int zk_prove_batch_collect(zk_ctx *ctx, zk_partials *out, uint32_t k, zk_timings *t);
+/* ---- sharded latency mode, SURVEY 8(e) option 2: the three transform chains of the witness map (row evaluations of A, B or C,
+ * iFFT, cosetFFT) run on three different ranks instead of being replicated on all of them.
+ *   zk_chain_submit         queue chain `which` (0 A, 1 B, 2 C) of this witness; its m coset evaluations end up at zk_chain_device
+ *   zk_h_from_chains_submit queue (a b - c) / Z on the coset + icosetFFT from three chain buffers in THIS device's memory
+ *                           (received from the other ranks); h ends up at zk_h_device (m elements)
+ *   zk_chain_wait           wait for what was queued (check_degree: ZK_ERR_DEGREE unless h[m-1] = 0)
+ *   zk_prove_submit_with_h  zk_prove_submit that takes this shard's coefficients of H -- h[lo .. hi), lo = (m-1) rank / count,
+ *                           hi = (m-1) (rank+1) / count -- from a device buffer instead of computing H; collect as usual */
+int zk_chain_submit(zk_ctx *ctx, const uint64_t *witness, int canonical, int which);
+const void *zk_chain_device(const zk_ctx *ctx, int which);
+int zk_h_from_chains_submit(zk_ctx *ctx, const void *dA, const void *dB, const void *dC);
+const void *zk_h_device(const zk_ctx *ctx);
+int zk_chain_wait(zk_ctx *ctx, int check_degree);
+int zk_prove_submit_with_h(zk_ctx *ctx, const uint64_t *witness, int canonical, const void *d_h);
 /* zk_prove_submit for a witness that is already resident in the context's device memory (d_witness = device
  * pointer to (V + 1) x 32 bytes, e.g. written by a GPU witness generator); it must stay untouched until collected */
 int zk_prove_submit_resident(zk_ctx *ctx, const void *d_witness, int canonical);

@@ -35,7 +35,8 @@ def _worker(rank, world, port, emul_so, q):
     sp = ShardedProver(ctx, dist, torch.device("cpu"))
     got = P.proof_to_json(sp.prove_struct(wm), wm[1:2])
     got2 = P.proof_to_json(sp.prove_struct(wm, timings=True)[0], wm[1:2])
-    q.put((rank, got == expect and got2 == expect and shared))
+    got3 = P.proof_to_json(sp.prove_struct_split_witness_map(wm), wm[1:2])      # SURVEY 8(e) option 2 (three ranks or more)
+    q.put((rank, got == expect and got2 == expect and got3 == expect and shared))
     dist.barrier()
     dist.destroy_process_group()
 
