@@ -230,10 +230,10 @@ def main():
                                          "matches_replica_proof": s2["json"] == js}
             except Exception as e:                              # the headline line must survive a failure of an extra leg
                 extras["msm_sharded"] = {"error": repr(e)[:300]}
-            if world >= 3:                                      # SURVEY 8(e) option 2: A / B / C transform chains on three ranks, one proof at a time
+            if world >= 3 and not gloo:                         # SURVEY 8(e) option 2: A / B / C transform chains on three ranks, one proof at a time
                 try:
                     ctx2 = P.ProverContext(pk, r1cs, multi_exp_c=args.multi_exp_c, device=local_rank, shard_rank=rank, shard_count=world)
-                    sp2 = ShardedProver(ctx2, dist, "cpu" if gloo else torch.device("cuda", local_rank))
+                    sp2 = ShardedProver(ctx2, dist, torch.device("cuda", local_rank))
                     lat = {}
                     for name, fn in (("split_witness_map", sp2.prove_struct_split_witness_map), ("replicated_witness_map", sp2.prove_struct)):
                         fn(wm); sync()
