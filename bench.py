@@ -193,10 +193,10 @@ def main():
             # one more (untimed) proof with every launch bracketed by HIP events: sum of kernel durations per proof
             P.profile_begin()
             ctxs[0].submit_resident(d_w.data_ptr()) if d_w is not None else ctxs[0].submit(wm)
-            ctxs[0].collect()
+            _, t_alone = ctxs[0].collect()
             s_ms, n_l, per = P.profile_end()
             top = sorted(per.items(), key=lambda kv: -kv[1][1])[:6]
-            ksum = {"kernel_ms_sum_one_proof_alone": round(s_ms, 3), "launches": n_l,
+            ksum = {"kernel_ms_sum_one_proof_alone": round(s_ms, 3), "launches": n_l, "acc_b_ms_alone": round(t_alone["acc_b"], 4),
                     "top": {k.strip("()"): {"calls": c, "ms": round(v, 3)} for k, (c, v) in top}}
         for c in ctxs:
             c.close()
@@ -308,6 +308,13 @@ def main():
         if out["kernel_sum"] is not None:
             out["kernel_sum"]["note"] = ("HIP-event durations of every launch of one proof run alone, overlapping tails counted each; the timed steps keep %d proofs in flight, "
                                          "so ms_per_step (%.2f) is below this sum" % (max(1, args.inflight), out["ms_per_step"]))
+        if out["kernel_sum"] is not None and out["kernel_sum"].get("acc_b_ms_alone", 0) > 0:
+            alone = out["kernel_sum"]["acc_b_ms_alone"]
+            out["roofline"]["alone"] = {"avg_launch_ms": alone, "achieved": round(alg_bytes / (alone * 1e-3) / 1e9, 3),
+                                        "frac": round(alg_bytes / (alone * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6),
+                                        "valu_frac": round(mads / (alone * 1e-3) / mad_peak, 4),
+                                        "note": "the same kernel when one proof runs alone; in the timed steps the accumulations of %d proofs share the machine "
+                                                "(low-priority stream) with each other and with the sorts / transforms, which stretches every launch" % max(1, args.inflight)}
         out.update(extras)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], out["parity_vs_oracle"] = cpu_baseline(args, P, R, F, pk, r1cs, wm, js, logm, local_rank)
