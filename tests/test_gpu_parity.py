@@ -401,3 +401,15 @@ def test_stub_test_proof_verify_and_static_triple(hip):
     d = json.load(open(os.path.join(GOLDEN, "ref_static_triple.json")))
     assert hip.stub_verify(json.dumps(d["vk"]), json.dumps(d["proof"]))
     assert not hip.stub_verify(json.dumps(d["vk"]), json.dumps(dict(d["proof"], C=d["proof"]["A"])))
+
+
+def test_sharded_device_exchange_over_rccl_one_rank(hip):
+    """The device-buffer exchange of sharded provers on real hardware as far as one GPU allows (tests/rccl_one_rank.py, run
+    as a child process so that torch initialises the GPU before the library does, as in bench.py): a context that owns shard
+    0 of 2 leaves its partial sums in its 640-byte device buffer, torch wraps that buffer without a copy, RCCL ("nccl", world
+    size 1) all-gathers it, zk_prove_combine_device folds the gathered record; the two shards folded together give the
+    oracle's proof."""
+    import os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    p = subprocess.run([sys.executable, os.path.join(here, "rccl_one_rank.py")], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "RCCL_ONE_RANK_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
