@@ -11,7 +11,7 @@
 // P_k is expanded to its W window multiples  T[w][k] = 2^(c*w) * P_k  (affine, W*n points: 1 GB per G1
 // query at n = 2^20, c = 16).  A signed digit d of window w of scalar k then contributes sign(d) * T[w][k]
 // to bucket |d| of ONE shared set of 2^(c-1) buckets: no per-window bucket sets, no window Horner,
-// 16x fewer buckets to reduce, ~n*W/2^(c-1) entries per bucket so fixed-length segments are full.
+// 16x fewer buckets to reduce, ~n*W/2^(c-1) entries per bucket (240 at n = 2^20, c = 17).
 //
 // Per proof (integer VALU work; random 64/128-B gathers from the table):
 //   1 k_sort_count / k_sort_colscan / k_sort_binscan / k_sort_partition   scalar -> signed c-bit digits ->
@@ -27,7 +27,7 @@
 // additions rather than a throughput problem (MsmShape::quad / quad_acc).
 // Zero scalars produce no entries; scalar 1 (and any repeated value) lands in one bucket whose entries
 // are cut into chunk pieces, so 0/1-heavy witnesses (the *_with_mixed_addition fast paths of the reference)
-// stay load-balanced without special cases; buckets with very many segments go to a workgroup reducer.
+// stay load-balanced without special cases; buckets with very many chunk pieces go to a workgroup reducer.
 #pragma once
 #include "bn254.hpp"
 #include "common.hpp"
@@ -102,7 +102,7 @@ struct MsmShape {
     uint32_t group = MSM_GROUP;     // buckets per running-sum thread
     ChunkRule chunk;
     uint32_t quad = 1;      // lanes per logical thread in the bucket-reduction kernels: 1, or 4 (Curve::*_q) for latency-bound sizes
-    uint32_t quad_acc = 1;  // ... and in the accumulation kernel (only while 4 lanes per segment still fit the machine at once)
+    uint32_t quad_acc = 1;  // ... and in the accumulation kernel (only while 4 lanes per chunk still fit the machine at once)
     // largest window with >= 32 entries per bucket on average (n * W entries over 2^(c-1) buckets)
     static uint32_t pick_c(uint32_t n) {
         for (uint32_t c = 17; c > 2; c--)      // 17: measured optimum at n = 2^20 (W = 15 windows, 2^16 buckets)
@@ -162,7 +162,7 @@ struct MsmWork {
     uint32_t *counts = nullptr, *bin_total = nullptr, *bin_base = nullptr;
     uint32_t *off = nullptr, *sorted = nullptr;
     uint32_t *heavy_list = nullptr, *heavy_count = nullptr;
-    typename C::XYZZ *segsum = nullptr, *bucket = nullptr, *partial_a = nullptr, *partial_b = nullptr;
+    typename C::XYZZ *pieces = nullptr, *bucket = nullptr, *partial_a = nullptr, *partial_b = nullptr;
     typename C::XYZZ *host_result = nullptr;    // pinned, max_batch entries
     typename C::XYZZ *dev_result = nullptr;     // optional: a device copy of the results as well, one every dev_result_pitch bytes (sharded provers exchange it with RCCL)
     size_t dev_result_pitch = 0;
@@ -171,7 +171,7 @@ struct MsmWork {
 
     // shared_table: an already expanded table of exactly these n bases (same c) to borrow; nullptr: allocate one.
     // sort_like: this MSM will be driven by ANOTHER MsmWork's sort (same scalars: A-, B- and L-query all read the
-    // witness): take that shape (same c, W, buckets, segment length), size the reduction buffers for its entries,
+    // witness): take that shape (same c, W, buckets, chunk rule), size the reduction buffers for its entries,
     // and do not allocate sort buffers of its own.
     // sort_only: no table and no reduction buffers -- this object only sorts a scalar vector for others.
     int alloc(uint32_t n, uint32_t c, typename C::Affine *shared_table = nullptr, const MsmShape *sort_like = nullptr, bool sort_only = false, uint32_t batch = 1);

@@ -350,7 +350,7 @@ int MsmWork<C>::alloc(uint32_t n, uint32_t c, typename C::Affine *shared_table, 
     const uint64_t pieces = sh.chunk.max_chunks(sh.max_entries() * B) + sh.nb * B + 1;
     ZK_HIP(hipMalloc(&heavy_list, sizeof(uint32_t) * (pieces / MSM_HEAVY + 2)));
     ZK_HIP(hipMalloc(&heavy_count, sizeof(uint32_t)));
-    ZK_HIP(hipMalloc(&segsum, sizeof(typename C::XYZZ) * pieces));
+    ZK_HIP(hipMalloc(&this->pieces, sizeof(typename C::XYZZ) * pieces));
     ZK_HIP(hipMalloc(&bucket, sizeof(typename C::XYZZ) * sh.nb * B));
     ZK_HIP(hipMalloc(&partial_a, sizeof(typename C::XYZZ) * ((size_t)groups * B + 1)));
     ZK_HIP(hipMalloc(&partial_b, sizeof(typename C::XYZZ) * ((size_t)zk_div_up(groups, MSM_TREE / sh.quad) * B + 1)));
@@ -362,7 +362,7 @@ int MsmWork<C>::alloc(uint32_t n, uint32_t c, typename C::Affine *shared_table, 
 template <class C>
 void MsmWork<C>::release() {
     if (!owns_table) table = nullptr;
-    void *dev[] = {table, pairs, counts, bin_total, bin_base, off, sorted, heavy_list, heavy_count, segsum, bucket, partial_a, partial_b};
+    void *dev[] = {table, pairs, counts, bin_total, bin_base, off, sorted, heavy_list, heavy_count, pieces, bucket, partial_a, partial_b};
     for (void *p : dev) if (p) hipFree(p);
     if (host_result) hipHostFree(host_result);
     if (ev_acc0) hipEventDestroy(ev_acc0);
@@ -409,8 +409,8 @@ template <class C>
 template <int Q>
 int MsmWork<C>::launch_reduce(uint32_t K, uint32_t groups, hipStream_t st) {      // groups: per proof
     const uint32_t nb = sh.nb * cur_batch, all_groups = groups * cur_batch;
-    ZK_LAUNCH((k_msm_bucket_finalize<C, Q>), zk_div_up((uint64_t)nb * Q, 64), 64, st, (const typename C::XYZZ *)segsum, (const uint32_t *)cur_off, nb, sh.chunk, bucket, heavy_list, heavy_count);
-    ZK_LAUNCH_SYNC((k_msm_heavy<C, Q>), MSM_HEAVY_GRID, 128 * Q, st, (const typename C::XYZZ *)segsum, (const uint32_t *)cur_off, nb, sh.chunk,
+    ZK_LAUNCH((k_msm_bucket_finalize<C, Q>), zk_div_up((uint64_t)nb * Q, 64), 64, st, (const typename C::XYZZ *)pieces, (const uint32_t *)cur_off, nb, sh.chunk, bucket, heavy_list, heavy_count);
+    ZK_LAUNCH_SYNC((k_msm_heavy<C, Q>), MSM_HEAVY_GRID, 128 * Q, st, (const typename C::XYZZ *)pieces, (const uint32_t *)cur_off, nb, sh.chunk,
                    (const uint32_t *)heavy_list, (const uint32_t *)heavy_count, bucket);
     ZK_LAUNCH((k_msm_group_reduce<C, Q>), zk_div_up((uint64_t)all_groups * Q, 64), 64, st, (const typename C::XYZZ *)bucket, nb, K, groups, partial_a);
     typename C::XYZZ *cur = partial_a, *nxt = partial_b;
@@ -437,10 +437,10 @@ int MsmWork<C>::enqueue_reduce(const SortView &v, hipStream_t st, hipStream_t st
     ZK_HIP(hipEventRecord(ev_acc0, st));
     if (sh.quad_acc == 4)
         ZK_LAUNCH((k_msm_accumulate<C, 4>), zk_div_up(max_seg * 4, 64), 64, st, (const typename C::Affine *)table, v.sorted, v.off,
-                  nb, sh.chunk, v.remap_src, v.remap_offset, v.remap_pos, table_n, segsum);
+                  nb, sh.chunk, v.remap_src, v.remap_offset, v.remap_pos, table_n, pieces);
     else
         ZK_LAUNCH((k_msm_accumulate<C, 1>), zk_div_up(max_seg, 64), 64, st, (const typename C::Affine *)table, v.sorted, v.off,
-                  nb, sh.chunk, v.remap_src, v.remap_offset, v.remap_pos, table_n, segsum);
+                  nb, sh.chunk, v.remap_src, v.remap_offset, v.remap_pos, table_n, pieces);
     ZK_HIP(hipEventRecord(ev_acc1, st));
     if (st_tail != st) { ZK_HIP(hipStreamWaitEvent(st_tail, ev_acc1, 0)); st = st_tail; }
     cur_off = v.off;
