@@ -347,10 +347,10 @@ int MsmWork<C>::alloc(uint32_t n, uint32_t c, typename C::Affine *shared_table, 
         ZK_HIP(hipMalloc(&off, sizeof(uint32_t) * (sh.nb * B + 1)));
     }
     if (sort_only) return ZK_OK;
-    const uint64_t pieces = sh.chunk.max_chunks(sh.max_entries() * B) + sh.nb * B + 1;
-    ZK_HIP(hipMalloc(&heavy_list, sizeof(uint32_t) * (pieces / MSM_HEAVY + 2)));
+    const uint64_t n_pieces = sh.chunk.max_chunks(sh.max_entries() * B) + sh.nb * B + 1;
+    ZK_HIP(hipMalloc(&heavy_list, sizeof(uint32_t) * (n_pieces / MSM_HEAVY + 2)));
     ZK_HIP(hipMalloc(&heavy_count, sizeof(uint32_t)));
-    ZK_HIP(hipMalloc(&this->pieces, sizeof(typename C::XYZZ) * pieces));
+    ZK_HIP(hipMalloc(&pieces, sizeof(typename C::XYZZ) * n_pieces));
     ZK_HIP(hipMalloc(&bucket, sizeof(typename C::XYZZ) * sh.nb * B));
     ZK_HIP(hipMalloc(&partial_a, sizeof(typename C::XYZZ) * ((size_t)groups * B + 1)));
     ZK_HIP(hipMalloc(&partial_b, sizeof(typename C::XYZZ) * ((size_t)zk_div_up(groups, MSM_TREE / sh.quad) * B + 1)));
