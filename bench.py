@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary legs (host-witness rate, sharded legs, kernel sum)")
     ap.add_argument("--cpu-1t-logm", type=int, default=16, help="size of the one-thread CPU sample (a full 2^20 proof takes a minute on one core)")
     ap.add_argument("--shard-logm", type=int, default=22, help="size of the config-5 sharded leg at N > 1")
+    ap.add_argument("--extras-timeout", type=int, default=420, help="N > 1: seconds the secondary legs may take before the headline line is printed without them")
     args = ap.parse_args()
 
     import numpy as np
@@ -210,53 +211,58 @@ def main():
     head = run_leg(pk, r1cs, wm, shard, args.steps, args.warmup, args.witness)
     value, elapsed, acc_b, last_t, js = head["value"], head["elapsed"], head["acc_b"], head["timings"], head["json"]
     extras = {}
-    if not args.no_extras:
-        short = max(3, min(args.steps, 10))
-        try:
-            other = "host" if args.witness == "resident" else "resident"
-            h2 = run_leg(pk, r1cs, wm, shard, short, 2, other)
-            extras["%s_witness" % other] = {"value": round(h2["value"], 4), "unit": "proofs/s", "steps": short,
-                                           "ms_per_step": round(1e3 * h2["elapsed"] / short, 3),
-                                           "note": ("witness handed over as a host buffer: its %.1f MB H2D copy is inside the timed region (PCIe-inclusive rate)" % (32 * (r1cs.V + 1) / 1e6))
-                                                   if other == "host" else "witness resident in HBM"}
-        except Exception as e:
-            extras["other_witness"] = {"error": repr(e)[:300]}
-        if world > 1 and mode == "replicas":
+
+    def run_extras():
+        if args.no_extras:
+            return
+        if True:
+            short = max(3, min(args.steps, 10))
             try:
-                s2 = run_leg(pk, r1cs, wm, True, short, 2, args.witness)
-                extras["msm_sharded"] = {"value": round(s2["value"], 4), "unit": "proofs/s", "scaling": "strong", "steps": short,
-                                         "ms_per_step": round(1e3 * s2["elapsed"] / short, 3),
-                                         "parallelism": "msm-shard%d + RCCL all-gather of 640 B partials (device buffers)" % world,
-                                         "matches_replica_proof": s2["json"] == js}
-            except Exception as e:                              # the headline line must survive a failure of an extra leg
-                extras["msm_sharded"] = {"error": repr(e)[:300]}
-            if world >= 3 and not gloo:                         # SURVEY 8(e) option 2: A / B / C transform chains on three ranks, one proof at a time
+                other = "host" if args.witness == "resident" else "resident"
+                h2 = run_leg(pk, r1cs, wm, shard, short, 2, other)
+                extras["%s_witness" % other] = {"value": round(h2["value"], 4), "unit": "proofs/s", "steps": short,
+                                               "ms_per_step": round(1e3 * h2["elapsed"] / short, 3),
+                                               "note": ("witness handed over as a host buffer: its %.1f MB H2D copy is inside the timed region (PCIe-inclusive rate)" % (32 * (r1cs.V + 1) / 1e6))
+                                                       if other == "host" else "witness resident in HBM"}
+            except Exception as e:
+                extras["other_witness"] = {"error": repr(e)[:300]}
+            if world > 1 and mode == "replicas":
                 try:
-                    ctx2 = P.ProverContext(pk, r1cs, multi_exp_c=args.multi_exp_c, device=local_rank, shard_rank=rank, shard_count=world)
-                    sp2 = ShardedProver(ctx2, dist, torch.device("cuda", local_rank))
-                    lat = {}
-                    for name, fn in (("split_witness_map", sp2.prove_struct_split_witness_map), ("replicated_witness_map", sp2.prove_struct)):
-                        fn(wm); sync()
-                        t0 = time.perf_counter()
-                        for _ in range(short):
-                            pr = fn(wm)
-                        sync()
-                        lat[name] = {"ms_per_proof": round(1e3 * (time.perf_counter() - t0) / short, 3), "matches_replica_proof": P.proof_to_json(pr, wm[1:1 + r1cs.nIn]) == js}
-                    extras["msm_sharded_latency"] = dict(lat, note="one sharded proof at a time (no pipelining): witness map replicated on every rank vs its A / B / C chains on ranks 0-2 (SURVEY 8(e) option 2)")
-                    ctx2.close()
-                except Exception as e:
-                    extras["msm_sharded_latency"] = {"error": repr(e)[:300]}
-            if args.workload == "chain" and args.shard_logm and args.shard_logm != logm:
-                try:
-                    r5, w5, pk5, name5, _, _ = make_workload("chain", args.shard_logm)
-                    s5 = run_leg(pk5, r5, w5, True, max(3, short // 2), 1, args.witness)
-                    extras["msm_sharded_2p%d" % args.shard_logm] = {
-                        "value": round(s5["value"], 4), "unit": "proofs/s", "scaling": "strong", "steps": max(3, short // 2),
-                        "ms_per_step": round(1e3 * s5["elapsed"] / max(3, short // 2), 3), "constraints_per_sec": round(s5["value"] * r5.nC, 1),
-                        "workload": name5, "parallelism": "msm-shard%d + RCCL all-gather of 640 B partials (device buffers)" % world}
-                    pk5.close()
-                except Exception as e:
-                    extras["msm_sharded_2p%d" % args.shard_logm] = {"error": repr(e)[:300]}
+                    s2 = run_leg(pk, r1cs, wm, True, short, 2, args.witness)
+                    extras["msm_sharded"] = {"value": round(s2["value"], 4), "unit": "proofs/s", "scaling": "strong", "steps": short,
+                                             "ms_per_step": round(1e3 * s2["elapsed"] / short, 3),
+                                             "parallelism": "msm-shard%d + RCCL all-gather of 640 B partials (device buffers)" % world,
+                                             "matches_replica_proof": s2["json"] == js}
+                except Exception as e:                              # the headline line must survive a failure of an extra leg
+                    extras["msm_sharded"] = {"error": repr(e)[:300]}
+                if world >= 3 and not gloo:                         # SURVEY 8(e) option 2: A / B / C transform chains on three ranks, one proof at a time
+                    try:
+                        ctx2 = P.ProverContext(pk, r1cs, multi_exp_c=args.multi_exp_c, device=local_rank, shard_rank=rank, shard_count=world)
+                        sp2 = ShardedProver(ctx2, dist, torch.device("cuda", local_rank))
+                        lat = {}
+                        for name, fn in (("split_witness_map", sp2.prove_struct_split_witness_map), ("replicated_witness_map", sp2.prove_struct)):
+                            fn(wm); sync()
+                            t0 = time.perf_counter()
+                            for _ in range(short):
+                                pr = fn(wm)
+                            sync()
+                            lat[name] = {"ms_per_proof": round(1e3 * (time.perf_counter() - t0) / short, 3), "matches_replica_proof": P.proof_to_json(pr, wm[1:1 + r1cs.nIn]) == js}
+                        extras["msm_sharded_latency"] = dict(lat, note="one sharded proof at a time (no pipelining): witness map replicated on every rank vs its A / B / C chains on ranks 0-2 (SURVEY 8(e) option 2)")
+                        ctx2.close()
+                    except Exception as e:
+                        extras["msm_sharded_latency"] = {"error": repr(e)[:300]}
+                if args.workload == "chain" and args.shard_logm and args.shard_logm != logm:
+                    try:
+                        r5, w5, pk5, name5, _, _ = make_workload("chain", args.shard_logm)
+                        s5 = run_leg(pk5, r5, w5, True, max(3, short // 2), 1, args.witness)
+                        extras["msm_sharded_2p%d" % args.shard_logm] = {
+                            "value": round(s5["value"], 4), "unit": "proofs/s", "scaling": "strong", "steps": max(3, short // 2),
+                            "ms_per_step": round(1e3 * s5["elapsed"] / max(3, short // 2), 3), "constraints_per_sec": round(s5["value"] * r5.nC, 1),
+                            "workload": name5, "parallelism": "msm-shard%d + RCCL all-gather of 640 B partials (device buffers)" % world}
+                        pk5.close()
+                    except Exception as e:
+                        extras["msm_sharded_2p%d" % args.shard_logm] = {"error": repr(e)[:300]}
+
 
     out = None
     if rank == 0:
@@ -315,6 +321,24 @@ def main():
                                         "valu_frac": round(mads / (alone * 1e-3) / mad_peak, 4),
                                         "note": "the same kernel when one proof runs alone; in the timed steps the accumulations of %d proofs share the machine "
                                                 "(low-priority stream) with each other and with the sorts / transforms, which stretches every launch" % max(1, args.inflight)}
+    # secondary legs.  At N > 1 they contain collectives this builder could only rehearse (gloo / one RCCL rank): a watchdog
+    # makes sure the headline line is printed even if one of them stalls.
+    def bail():
+        if rank == 0:
+            out.update(extras)
+            out["extras_aborted"] = "secondary legs did not finish within %d s; headline unaffected" % args.extras_timeout
+            print(json.dumps(out), flush=True)
+        os._exit(0)
+    watchdog = None
+    if world > 1 and not args.no_extras:
+        import threading
+        watchdog = threading.Timer(args.extras_timeout, bail)
+        watchdog.daemon = True
+        watchdog.start()
+    run_extras()
+    if watchdog is not None:
+        watchdog.cancel()
+    if rank == 0:
         out.update(extras)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], out["parity_vs_oracle"] = cpu_baseline(args, P, R, F, pk, r1cs, wm, js, logm, local_rank)
