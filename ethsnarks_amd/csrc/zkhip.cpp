@@ -1123,6 +1123,128 @@ extern "C" int zk_keygen(const zk_csr *A, const zk_csr *B, const zk_csr *C, uint
     return ZK_OK;
 }
 
+// ================================================================ witness completion on the GPU
+// The reference fills pb.values on the host, gadget by gadget (generate_r1cs_witness).  For circuits whose constraints are in
+// "solved order" -- every constraint reads known variables in A and B and introduces at most ONE new variable, linearly, in C;
+// true of the MiMC / Merkle gadgets and of the synthetic chain -- the constraint system itself is the witness program:
+//     w[t_j] = (<A_j, w> <B_j, w> - sum_{i != t_j} C_ji w_i) / C_{j t_j}
+// A plan (zk_wplan) is that program compiled once; zk_wplan_solve runs it for k witnesses at a time, one thread per witness
+// (the k threads walk the same constraints in lock step: no divergence), directly in the buffer zk_prove_batch_submit_resident
+// then proves from -- the witnesses never visit the host.  Constraints that introduce nothing are checked instead.
+namespace {
+__global__ void k_witness_solve(const uint32_t *__restrict__ a_ptr, const uint32_t *__restrict__ a_col, const fe *__restrict__ a_cf,
+                                const uint32_t *__restrict__ b_ptr, const uint32_t *__restrict__ b_col, const fe *__restrict__ b_cf,
+                                const uint32_t *__restrict__ c_ptr, const uint32_t *__restrict__ c_col, const fe *__restrict__ c_cf,
+                                const uint32_t *__restrict__ target, const fe *__restrict__ inv, uint32_t nC,
+                                fe *__restrict__ w, uint32_t stride, uint32_t k, uint32_t *__restrict__ violations) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= k) return;
+    fe *x = w + (size_t)p * stride;
+    uint32_t bad = 0;
+    for (uint32_t j = 0; j < nC; j++) {
+        fe a = Fr::zero(), b = Fr::zero(), s = Fr::zero();
+        for (uint32_t e = a_ptr[j]; e < a_ptr[j + 1]; e++) a = Fr::add(a, spmv_term(a_cf[e], x[a_col[e]]));
+        for (uint32_t e = b_ptr[j]; e < b_ptr[j + 1]; e++) b = Fr::add(b, spmv_term(b_cf[e], x[b_col[e]]));
+        const uint32_t t = target[j];
+        for (uint32_t e = c_ptr[j]; e < c_ptr[j + 1]; e++) if (c_col[e] != t) s = Fr::add(s, spmv_term(c_cf[e], x[c_col[e]]));
+        fe v = Fr::sub(Fr::mul(a, b), s);
+        if (t == 0xffffffffu) { bad += !Fr::is_zero(v); continue; }
+        const fe iv = inv[j];
+        x[t] = fr_is_one(iv) ? v : Fr::mul(v, iv);
+    }
+    if (bad) atomicAdd(violations, bad);
+}
+}  // namespace
+
+struct zk_wplan {
+    int device = 0;
+    uint32_t nC = 0, V = 0;
+    DevCsr A, B, C;
+    uint32_t *d_target = nullptr, *d_viol = nullptr;
+    fe *d_inv = nullptr;
+    hipStream_t st = nullptr;
+    ~zk_wplan() {
+        hipSetDevice(device);
+        A.release(); B.release(); C.release();
+        if (d_target) hipFree(d_target);
+        if (d_viol) hipFree(d_viol);
+        if (d_inv) hipFree(d_inv);
+        if (st) hipStreamDestroy(st);
+    }
+};
+
+extern "C" int zk_wplan_create(const zk_csr *A, const zk_csr *B, const zk_csr *C, uint32_t nC, uint32_t V,
+                               const uint8_t *known, int device, zk_wplan **out) {
+    if (!A || !B || !C || !known || !out) return fail(ZK_ERR_ARG, "null argument");
+    if (A->n_rows != nC || B->n_rows != nC || C->n_rows != nC) return fail(ZK_ERR_ARG, "CSR row counts must equal nC");
+    ZK_TRY(use_device(device));
+    std::vector<uint8_t> have(known, known + (size_t)V + 1);
+    have[0] = 1;                                                     // the constant ONE
+    std::vector<uint32_t> target(nC, 0xffffffffu);
+    std::vector<fe> inv(nC, Fr::one());
+    char msg[200];
+    for (uint32_t j = 0; j < nC; j++) {
+        const zk_csr *M[2] = {A, B};
+        for (int q = 0; q < 2; q++)
+            for (uint32_t e = M[q]->row_ptr[j]; e < M[q]->row_ptr[j + 1]; e++) {
+                if (M[q]->col[e] > V) return fail(ZK_ERR_ARG, "CSR column index exceeds the number of variables");
+                if (!have[M[q]->col[e]]) { snprintf(msg, sizeof(msg), "constraint %u reads variable %u in %c before anything defines it: not in solved order", j, M[q]->col[e], q ? 'B' : 'A'); return fail(ZK_ERR_ARG, msg); }
+            }
+        for (uint32_t e = C->row_ptr[j]; e < C->row_ptr[j + 1]; e++) {
+            const uint32_t v = C->col[e];
+            if (v > V) return fail(ZK_ERR_ARG, "CSR column index exceeds the number of variables");
+            if (have[v]) continue;
+            if (target[j] != 0xffffffffu) { snprintf(msg, sizeof(msg), "constraint %u introduces two new variables (%u and %u)", j, target[j], v); return fail(ZK_ERR_ARG, msg); }
+            fe cf; memcpy(cf.l, C->coeff + 4 * (size_t)e, 32);
+            if (Fr::is_zero(cf)) return fail(ZK_ERR_ARG, "zero coefficient on the variable a constraint introduces");
+            target[j] = v;
+            if (!fr_is_one(cf)) inv[j] = Fr::inv(cf);
+        }
+        if (target[j] != 0xffffffffu) have[target[j]] = 1;
+    }
+    for (uint32_t v = 0; v <= V; v++) if (!have[v]) { snprintf(msg, sizeof(msg), "variable %u is neither supplied nor defined by a constraint", v); return fail(ZK_ERR_ARG, msg); }
+    zk_wplan *p = new (std::nothrow) zk_wplan();
+    if (!p) return ZK_ERR_NOMEM;
+    p->device = device; p->nC = nC; p->V = V;
+    int rc = p->A.upload(A, V, 1);
+    if (rc == ZK_OK) rc = p->B.upload(B, V, 1);
+    if (rc == ZK_OK) rc = p->C.upload(C, V, 1);
+    if (rc == ZK_OK) rc = dev_upload(&p->d_target, target.data(), target.size());
+    if (rc == ZK_OK) rc = dev_upload(&p->d_inv, inv.data(), inv.size());
+    if (rc == ZK_OK && hipMalloc(&p->d_viol, 4) != hipSuccess) rc = ZK_ERR_NOMEM;
+    if (rc == ZK_OK && hipStreamCreateWithFlags(&p->st, hipStreamNonBlocking) != hipSuccess) rc = ZK_ERR_HIP;
+    if (rc != ZK_OK) { delete p; return rc; }
+    *out = p;
+    return ZK_OK;
+}
+extern "C" void zk_wplan_free(zk_wplan *p) { delete p; }
+// d_w: k witnesses, (V + 1) x 32 bytes each, contiguous, device memory, Montgomery; the supplied variables (and ONE at index
+// 0) filled in.  Completes them in place; *violations = constraints (over all k) that introduce nothing and do not hold.
+extern "C" int zk_wplan_solve(zk_wplan *p, void *d_w, uint32_t k, uint32_t *violations) {
+    if (!p || !d_w || !k) return fail(ZK_ERR_ARG, "bad argument");
+    ZK_TRY(use_device(p->device));
+    ZK_HIP(hipMemsetAsync(p->d_viol, 0, 4, p->st));
+    ZK_LAUNCH(k_witness_solve, zk_div_up(k, 64), 64, p->st, (const uint32_t *)p->A.row_ptr, (const uint32_t *)p->A.col, (const fe *)p->A.coeff,
+              (const uint32_t *)p->B.row_ptr, (const uint32_t *)p->B.col, (const fe *)p->B.coeff,
+              (const uint32_t *)p->C.row_ptr, (const uint32_t *)p->C.col, (const fe *)p->C.coeff,
+              (const uint32_t *)p->d_target, (const fe *)p->d_inv, p->nC, (fe *)d_w, p->V + 1, k, p->d_viol);
+    uint32_t v = 0;
+    ZK_HIP(hipMemcpyAsync(&v, p->d_viol, 4, hipMemcpyDeviceToHost, p->st));
+    ZK_HIP(hipStreamSynchronize(p->st));
+    if (violations) *violations = v;
+    return ZK_OK;
+}
+// plain device-memory helpers for hosts that have no HIP binding of their own (tests, ctypes clients)
+extern "C" int zk_dev_alloc(size_t bytes, int device, void **out) {
+    if (!out) return fail(ZK_ERR_ARG, "null argument");
+    ZK_TRY(use_device(device));
+    ZK_HIP(hipMalloc(out, bytes ? bytes : 1));
+    return ZK_OK;
+}
+extern "C" int zk_dev_free(void *p) { return (!p || hipFree(p) == hipSuccess) ? ZK_OK : ZK_ERR_HIP; }
+extern "C" int zk_dev_upload(void *dst, const void *src, size_t bytes) { if (!dst || !src) return fail(ZK_ERR_ARG, "null argument"); ZK_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return ZK_OK; }
+extern "C" int zk_dev_download(void *dst, const void *src, size_t bytes) { if (!dst || !src) return fail(ZK_ERR_ARG, "null argument"); ZK_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return ZK_OK; }
+
 // ================================================================ JSON (src/export.cpp:20-121)
 namespace {
 // HexStringFromBigint = mpz_get_str(., 16, .): lowercase, no leading zeros, zero prints "0"

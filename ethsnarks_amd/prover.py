@@ -61,6 +61,7 @@ EXPORTS = [
     "zk_domain_size", "zk_ctx_create", "zk_ctx_destroy",
     "zk_prove", "zk_prove_timed", "zk_prove_partial", "zk_prove_partial_timed", "zk_prove_combine", "zk_prove_submit", "zk_prove_collect", "zk_proof_to_json",
     "zk_prove_batch", "zk_prove_batch_submit", "zk_prove_batch_submit_resident", "zk_prove_batch_collect",
+    "zk_wplan_create", "zk_wplan_solve", "zk_wplan_free", "zk_dev_alloc", "zk_dev_free", "zk_dev_upload", "zk_dev_download",
     "zk_chain_submit", "zk_chain_device", "zk_h_from_chains_submit", "zk_h_device", "zk_chain_wait", "zk_prove_submit_with_h",
     "zk_prove_submit_resident", "zk_ctx_info", "zk_ctx_partials_device", "zk_prove_collect_device", "zk_prove_combine_device", "zk_launch_count", "zk_profile_begin", "zk_profile_end", "zk_device_info",
     "zk_verify",
@@ -507,6 +508,69 @@ def stub_test_proof_verify(r1cs, witness, **kw):
         return stub_verify(vk.to_json(), prove(ctx, witness))
     finally:
         ctx.close()
+
+
+# ---- witness completion on the GPU
+class DeviceBuffer:
+    """device memory through the library (zk_dev_*): for hosts without a HIP binding of their own"""
+
+    def __init__(self, nbytes, device=0):
+        p = C.c_void_p()
+        _check(load_library(_lib_path_loaded).zk_dev_alloc(C.c_size_t(nbytes), device, C.byref(p)))
+        self.ptr, self.nbytes = p.value, nbytes
+
+    def upload(self, arr, offset=0):
+        a = np.ascontiguousarray(arr)
+        _check(_lib.zk_dev_upload(C.c_void_p(self.ptr + offset), a.ctypes.data_as(C.c_void_p), C.c_size_t(a.nbytes)))
+
+    def download(self, shape, dtype=np.uint64, offset=0):
+        out = np.zeros(shape, dtype=dtype)
+        _check(_lib.zk_dev_download(out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr + offset), C.c_size_t(out.nbytes)))
+        return out
+
+    def free(self):
+        if self.ptr and _lib is not None:
+            _lib.zk_dev_free(C.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class WitnessPlan:
+    """zk_wplan: the constraint system as a witness program (forward substitution), run on the GPU for k witnesses at a time.
+    `known`: indices of the variables the caller supplies (ONE is implied)."""
+
+    def __init__(self, r1cs, known, device=0):
+        lib = load_library(_lib_path_loaded)
+        flags = np.zeros(r1cs.V + 1, dtype=np.uint8)
+        flags[np.asarray(list(known), dtype=np.int64)] = 1
+        keep = []
+        a, b, c = _csr_structs(r1cs, keep)
+        h = C.c_void_p()
+        _check(lib.zk_wplan_create(C.byref(a), C.byref(b), C.byref(c), C.c_uint32(r1cs.nC), C.c_uint32(r1cs.V),
+                                   flags.ctypes.data_as(C.POINTER(C.c_uint8)), device, C.byref(h)))
+        self._h, self.r1cs = h, r1cs
+
+    def solve(self, device_ptr, k):
+        """complete k witnesses in place (device memory); returns the number of violated check constraints"""
+        bad = C.c_uint32(0)
+        _check(_lib.zk_wplan_solve(self._h, C.c_void_p(device_ptr), C.c_uint32(k), C.byref(bad)))
+        return int(bad.value)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and _lib is not None:
+            _lib.zk_wplan_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 # ---- measurement aids

@@ -57,6 +57,7 @@ extern "C" {
 typedef struct zk_pk zk_pk;
 typedef struct zk_vk zk_vk;
 typedef struct zk_ctx zk_ctx;
+typedef struct zk_wplan zk_wplan;
 
 typedef struct {
     uint32_t n_rows;
@@ -210,6 +211,23 @@ int zk_proof_to_json(const zk_proof *proof, const uint64_t *inputs, uint32_t nIn
 int zk_verify(const char *vk_json, const char *proof_json, int *accepted);
 /* same symbol and signature as the reference's libethsnarks_verify (src/verify_dll.cpp:3-10) */
 bool ethsnarks_verify(const char *vk_json, const char *proof_json);
+
+/* ---- witness completion on the GPU (the reference fills pb.values on the host, gadget by gadget).  For a
+ * constraint system in "solved order" -- every constraint reads known variables in A and B and introduces at most one new
+ * variable, linearly, in C (the MiMC / Merkle gadgets, the synthetic chain) -- the system itself is the witness program.
+ *   zk_wplan_create  compiles it; known[v] != 0 marks the variables the caller will supply (V + 1 flags; ONE is implied);
+ *                    ZK_ERR_ARG with an explanatory message when the constraints are not in solved order
+ *   zk_wplan_solve   completes k witnesses in place: d_w = device pointer to k x (V + 1) Fr elements (Montgomery), supplied
+ *                    variables filled in; *violations = constraints that introduce nothing and do not hold (0 = all satisfied).
+ *                    The buffer can go straight to zk_prove_batch_submit_resident: the witnesses never visit the host.
+ * zk_dev_*: device-memory helpers for hosts without a HIP binding of their own. */
+int zk_wplan_create(const zk_csr *A, const zk_csr *B, const zk_csr *C, uint32_t nC, uint32_t V, const uint8_t *known, int device, zk_wplan **out);
+int zk_wplan_solve(zk_wplan *plan, void *d_w, uint32_t k, uint32_t *violations);
+void zk_wplan_free(zk_wplan *plan);
+int zk_dev_alloc(size_t bytes, int device, void **out);
+int zk_dev_free(void *p);
+int zk_dev_upload(void *dst, const void *src, size_t bytes);
+int zk_dev_download(void *dst, const void *src, size_t bytes);
 
 /* ---- measurement aids (bench.py): kernel launches issued by this library so far; between zk_profile_begin() and
  * zk_profile_end() every launch is bracketed by a HIP event pair on its own stream -- the sum of the kernel durations

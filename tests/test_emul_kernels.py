@@ -216,3 +216,39 @@ def test_prove_batch_chain_shared_sort(zk, oracle):
     parts, _ = ctx.collect_batch(k)
     assert [zk.proof_to_json(ctx.prove_combine(parts[p]), ws[p][1:2]) for p in range(2)] == expect[:2]
     ctx.close()
+
+
+def test_witness_plan_completes_witnesses_on_the_device(zk, oracle):
+    """zk_wplan: the MiMC hash circuit's constraint system, compiled as a forward-substitution program, fills in
+    k witnesses from their supplied variables only (digest, IV, message words) -- equal to the front end's witnesses -- and the
+    buffer goes straight to zk_prove_batch_submit_resident.  A wrong digest is reported as a violated constraint; a system
+    that is not in solved order is refused with an explanation."""
+    from ethsnarks_amd import gadgets as G
+    k = 3
+    r, w0, _ = G.mimc_preimage_circuit(2, seed=7)
+    full = [w0] + [G.mimc_preimage_circuit(2, seed=70 + p)[1] for p in range(1, k)]
+    supplied = list(range(0, 1 + 1 + 1 + 2))                       # ONE, digest, iv, m[0..1] (allocation order of the circuit)
+    plan = zk.WitnessPlan(r, supplied)
+    buf = zk.DeviceBuffer(32 * (r.V + 1) * k)
+    start = np.zeros((k, r.V + 1, 4), dtype=np.uint64)
+    for p in range(k):
+        start[p, supplied] = F.fr_to_mont([full[p][i] for i in supplied])
+    buf.upload(start)
+    assert plan.solve(buf.ptr, k) == 0
+    got = buf.download((k, r.V + 1, 4))
+    for p in range(k):
+        assert np.array_equal(got[p], F.fr_to_mont(full[p]))
+    pk_o, _ = oracle.keygen(r, seed=5)
+    pk = zk.ProvingKey.from_parts(**pk_o.parts())
+    ctx = zk.ProverContext(pk, r, max_batch=k)
+    ctx.submit_batch(None, device_ptr=buf.ptr, k=k)
+    parts, _ = ctx.collect_batch(k)
+    for p in range(k):
+        assert zk.proof_to_json(ctx.prove_combine(parts[p]), got[p][1:2]) == oracle.prove(pk_o, r, got[p])[0]
+    start[1, 1] = F.fr_to_mont([12345])[0]                          # a wrong digest: the final check constraint does not hold
+    buf.upload(start)
+    assert plan.solve(buf.ptr, k) == 1
+    with pytest.raises(zk.ZkError) as e:
+        zk.WitnessPlan(r, supplied[:-1])                            # a message word neither supplied nor defined
+    assert e.value.code == 1 and "solved order" in str(e.value)
+    ctx.close(); plan.close(); buf.free()

@@ -262,6 +262,41 @@ def test_prove_batch_merkle29(hip, oracle, k):
     ctx.close()
 
 
+def test_witness_plan_merkle29_on_device_then_batch_prove(hip, oracle):
+    """SURVEY 8(f)-4, the whole pipeline resident: the depth-29 Merkle circuit's constraint system compiled as a forward-
+    substitution program (zk_wplan) completes k witnesses on the GPU from the supplied variables only (root, address bits, path,
+    leaf, IVs), the buffer goes to zk_prove_batch_submit_resident, and every proof equals the oracle's proof of the witness the
+    host front end computes for the same inputs."""
+    import time
+    from ethsnarks_amd import gadgets as G
+    k = 4
+    cases = [G.merkle_membership_circuit(29)] + [
+        G.merkle_membership_circuit(29, leaf=2000 + p, address=(0x0f0f0f0f * (p + 3)) & ((1 << 29) - 1), path=[G.merkle_unique(d, 11 + p) for d in range(29)])
+        for p in range(1, k)]
+    r = cases[0][0]
+    supplied = list(range(0, 1 + 1 + 29 + 29 + 1 + 29))             # ONE, expected_root, address_bits, path, leaf, IVs (allocation order)
+    plan = hip.WitnessPlan(r, supplied)
+    start = np.zeros((k, r.V + 1, 4), dtype=np.uint64)
+    for p in range(k):
+        start[p, supplied] = F.fr_to_mont([cases[p][1][i] for i in supplied])
+    buf = hip.DeviceBuffer(32 * (r.V + 1) * k)
+    buf.upload(start)
+    t0 = time.perf_counter()
+    assert plan.solve(buf.ptr, k) == 0
+    print("zk_wplan_solve: %d Merkle-29 witnesses in %.1f ms" % (k, 1e3 * (time.perf_counter() - t0)))
+    got = buf.download((k, r.V + 1, 4))
+    for p in range(k):
+        assert np.array_equal(got[p], F.fr_to_mont(cases[p][1]))
+    pk, _ = hip.keygen(r, seed=29)
+    pk_o = oracle.pk_from_parts(pk.parts())
+    ctx = hip.ProverContext(pk, r, max_batch=k)
+    ctx.submit_batch(None, device_ptr=buf.ptr, k=k)
+    parts, _ = ctx.collect_batch(k)
+    for p in range(k):
+        assert hip.proof_to_json(ctx.prove_combine(parts[p]), got[p][1:2]) == oracle.prove(pk_o, r, got[p])[0]
+    ctx.close(); plan.close(); buf.free()
+
+
 def test_prove_batch_chain_shared_sort_and_odd_batch(hip, oracle):
     """dense queries (A-, B-, L-query on one shared witness sort), a batch that is not a power of two, the asynchronous form"""
     r, _ = R.synthetic_chain((1 << 12) - 2, 1)
