@@ -53,6 +53,7 @@ def main():
                     help="chain: the headline synthetic R1CS (configs 2/3/5 by --logm); merkle29 / mimc11: BASELINE configs 4 / 1 "
                          "(real MiMC circuits from ethsnarks_amd.gadgets; latency-sized, not the headline)")
     ap.add_argument("--multi-exp-c", type=int, default=0)
+    ap.add_argument("--one-stream", action="store_true", help="zk_config.schedule = ZK_SCHED_ONE_STREAM: every launch of a context on one stream (small circuits, many contexts)")
     ap.add_argument("--inflight", type=int, default=3,
                     help="prover contexts kept in flight per GPU (1 = one synchronous proof at a time)")
     ap.add_argument("--batch", type=int, default=1,
@@ -130,7 +131,7 @@ def main():
         """`warmup` untimed + `steps` timed proofs in one parallelisation"""
         kb = max(1, args.batch) if not shard else 1
         ctxs = [P.ProverContext(pk, r1cs, multi_exp_c=args.multi_exp_c, device=local_rank,
-                                shard_rank=rank if shard else 0, shard_count=world if shard else 1, max_batch=kb)
+                                shard_rank=rank if shard else 0, shard_count=world if shard else 1, max_batch=kb, one_stream=args.one_stream)
                 for _ in range(max(1, args.inflight))]
         wmk = np.ascontiguousarray(np.tile(np.ascontiguousarray(wm).reshape(1, -1), (kb, 1)))     # the batch: kb witnesses, contiguous
         d_w = torch.from_numpy(wmk.view(np.int64).copy()).cuda() if witness == "resident" else None
@@ -288,7 +289,7 @@ def main():
                        "parallelism": ("msm-shard%d+allgather640B" % world) if shard else ("replicas%d" % world if world > 1 else "1gpu"),
                        "multi_exp_c": info["B"]["c"], "windows": W,
                        "witness": "resident in HBM when the timed region starts" if args.witness == "resident" else "host buffer, H2D inside the timed region",
-                       "inflight": max(1, args.inflight), "proofs_per_step": max(1, args.batch) if not shard else 1, "device": devinfo},
+                       "inflight": max(1, args.inflight), "schedule": "one stream per context" if args.one_stream else "overlap (five streams per context)", "proofs_per_step": max(1, args.batch) if not shard else 1, "device": devinfo},
             "roofline": {"kernel": "k_msm_accumulate<G2, 1> (B-query bucket accumulation)", "bound": "hbm",
                          "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic, "traffic_source": traffic_src,

@@ -650,7 +650,7 @@ static int ctx_build(zk_ctx *c, const zk_pk *pk, const zk_csr *A, const zk_csr *
     // polynomial pipeline; s_acc (low priority) carries the four machine-filling accumulation kernels, each released by
     // the event of its sort; the bucket-reduction tails run on side streams.  The priorities make the dispatcher hand freed
     // wave slots to the short kernels first, so the H pipeline advances in the shadow of the A-, B-, L-accumulations of the
-    // same proof instead of queueing behind them.  ZK_SERIAL=1 (profiling aid) puts everything on s_main;
+    // same proof instead of queueing behind them.  zk_config.schedule = ZK_SCHED_ONE_STREAM (or ZK_SERIAL=1) puts everything on s_main;
     // ZK_SPLIT_STREAMS=0 keeps the accumulations on s_main as well (the round-1 schedule).
     int prio_lo = 0, prio_hi = 0;
     ZK_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
@@ -662,7 +662,7 @@ static int ctx_build(zk_ctx *c, const zk_pk *pk, const zk_csr *A, const zk_csr *
     auto prio = [&](char ch) { return ch == 'h' ? prio_hi : ch == 'l' ? prio_lo : (prio_hi + prio_lo) / 2; };
     ZK_HIP(hipStreamCreateWithPriority(&c->s_main, hipStreamNonBlocking, prio(pr[0])));
     const char *serial = getenv("ZK_SERIAL");
-    c->serial = serial && serial[0] == '1';
+    c->serial = (serial && serial[0] == '1') || c->cfg.schedule == ZK_SCHED_ONE_STREAM;
     const char *split = getenv("ZK_SPLIT_STREAMS");
     if (c->serial || (split && split[0] == '0')) c->s_acc = c->s_main;
     else ZK_HIP(hipStreamCreateWithPriority(&c->s_acc, hipStreamNonBlocking, prio(pr[1])));

@@ -33,7 +33,7 @@ class ZkCSR(C.Structure):
 
 class ZkConfig(C.Structure):
     """libsnark::Config (src/prover_config.hpp:8-35) reduced to what a GPU prover consumes."""
-    _fields_ = [("multi_exp_c", C.c_uint32), ("device", C.c_uint32), ("shard_rank", C.c_uint32), ("shard_count", C.c_uint32), ("max_batch", C.c_uint32)]
+    _fields_ = [("multi_exp_c", C.c_uint32), ("device", C.c_uint32), ("shard_rank", C.c_uint32), ("shard_count", C.c_uint32), ("max_batch", C.c_uint32), ("schedule", C.c_uint32)]
 
 
 class ZkProof(C.Structure):
@@ -302,13 +302,14 @@ def get_domain_size(r1cs):
 class ProverContext:
     """ProverContext<ppT> (hpp:279-291) + get_domain: bases and CSR resident in HBM, scratch owned."""
 
-    def __init__(self, pk, r1cs, multi_exp_c=0, device=0, shard_rank=0, shard_count=1, max_batch=1):
+    def __init__(self, pk, r1cs, multi_exp_c=0, device=0, shard_rank=0, shard_count=1, max_batch=1, one_stream=False):
+        """one_stream: zk_config.schedule = ZK_SCHED_ONE_STREAM (many small proofs in many contexts)"""
         lib = load_library(_lib_path_loaded)
         self.r1cs = r1cs
         self.max_batch = max_batch
         self._keep = []
         a, b, c = _csr_structs(r1cs, self._keep)
-        cfg = ZkConfig(multi_exp_c, device, shard_rank, shard_count, max_batch)
+        cfg = ZkConfig(multi_exp_c, device, shard_rank, shard_count, max_batch, 1 if one_stream else 0)
         h = C.c_void_p()
         _check(lib.zk_ctx_create(pk._h, C.byref(a), C.byref(b), C.byref(c), C.c_uint32(r1cs.nC), C.c_uint32(r1cs.nIn),
                                  C.c_uint32(r1cs.V), C.byref(cfg), C.byref(h)))

@@ -75,7 +75,13 @@ typedef struct {
     uint32_t shard_rank;       /* MSM base-range sharding: this context owns shard_rank of shard_count */
     uint32_t shard_count;      /* 0 or 1 = unsharded */
     uint32_t max_batch;        /* proofs of this circuit one launch sequence may carry (zk_prove_batch); 0 or 1 = one at a time */
+    uint32_t schedule;         /* ZK_SCHED_OVERLAP (0): the proof's sorts, accumulations and reduction tails on five streams --
+                                * lowest latency of one proof, what large circuits want; ZK_SCHED_ONE_STREAM (1): every launch on one
+                                * stream -- for many small proofs in many contexts (a hardware queue runs its dispatches in order, so
+                                * fewer streams per context leave more queues to other contexts: profiles/r02_small_circuit_concurrency.txt) */
 } zk_config;
+#define ZK_SCHED_OVERLAP 0
+#define ZK_SCHED_ONE_STREAM 1
 
 /* canonical (non-Montgomery) affine coordinates; *_inf != 0 => point at infinity, printed as (0, 1) */
 typedef struct {

@@ -93,6 +93,9 @@ def test_prove_golden(zk, oracle, case):
     assert zk.prove(ctx, F.fr_to_mont(w)) == case["proof_json"]
     assert zk.prove(ctx, F.ints_to_limbs(w), canonical=True) == case["proof_json"]
     ctx.close()
+    one = zk.ProverContext(pk, r, one_stream=True)          # zk_config.schedule = ZK_SCHED_ONE_STREAM
+    assert zk.prove(one, F.fr_to_mont(w)) == case["proof_json"]
+    one.close()
 
 
 def test_prove_chain_long_rows_and_sharding(zk, oracle, tmp_path):

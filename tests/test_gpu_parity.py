@@ -153,6 +153,8 @@ def test_prove_random_circuits_vs_oracle(hip, oracle):
         ctx = hip.ProverContext(pk, r)
         expect, _ = oracle.prove(pk_o, r, wm)
         assert hip.prove(ctx, wm) == expect
+        one = hip.ProverContext(pk, r, one_stream=True)     # zk_config.schedule = ZK_SCHED_ONE_STREAM: same proof
+        assert hip.prove(one, wm) == expect and hip.prove(one, wm) == expect
 
 
 def test_errors(hip, oracle, tmp_path):
