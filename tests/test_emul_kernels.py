@@ -98,6 +98,18 @@ def test_prove_golden(zk, oracle, case):
     one.close()
 
 
+def test_prove_shape_sweep(zk, oracle):
+    """domain-size boundaries, no public inputs, a single constraint (the GPU suite sweeps 26 shapes up to 2^11)"""
+    for i, (nC, nIn) in enumerate([(1, 0), (3, 2), (7, 0), (62, 1), (63, 0), (127, 0)]):
+        r, w = R.random_r1cs(nC, nIn, n_extra_vars=i % 4, max_terms=1 + i % 8, seed=1000 + i, small_values=(i % 3 == 1))
+        wm = F.fr_to_mont(w)
+        pk_o, _ = oracle.keygen(r, seed=77 + i)
+        pk = zk.ProvingKey.from_parts(**pk_o.parts())
+        ctx = zk.ProverContext(pk, r, one_stream=bool(i & 1))
+        assert zk.prove(ctx, wm) == oracle.prove(pk_o, r, wm)[0], (nC, nIn)
+        ctx.close(); pk.close()
+
+
 def test_prove_chain_long_rows_and_sharding(zk, oracle, tmp_path):
     r, w = R.synthetic_chain(254, 1)                    # last row: 510 terms -> long-row path
     wm = F.fr_to_mont(w)

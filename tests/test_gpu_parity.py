@@ -157,6 +157,23 @@ def test_prove_random_circuits_vs_oracle(hip, oracle):
         assert hip.prove(one, wm) == expect and hip.prove(one, wm) == expect
 
 
+def test_prove_shape_sweep_vs_oracle(hip, oracle):
+    """domain-size boundaries (nC + nIn + 1 on either side of a power of two), no public inputs, one constraint, dense and
+    sparse rows, unreferenced variables, 0/1-heavy witnesses: every proof byte-equal to the oracle's"""
+    shapes = [(1, 0), (1, 1), (2, 0), (3, 2), (5, 1), (6, 1), (7, 0), (13, 2), (29, 2), (30, 1), (31, 0), (61, 2), (62, 1), (63, 0),
+              (126, 1), (127, 0), (250, 5), (254, 1), (255, 0), (509, 2), (1000, 3), (1021, 2), (1022, 1), (1023, 0), (2046, 1), (2047, 0)]
+    for i, (nC, nIn) in enumerate(shapes):
+        r, w = R.random_r1cs(nC, nIn, n_extra_vars=i % 4, max_terms=1 + i % 8, seed=1000 + i, small_values=(i % 3 == 1))
+        wm = F.fr_to_mont(w)
+        pk_o, _ = oracle.keygen(r, seed=77 + i)
+        expect, _ = oracle.prove(pk_o, r, wm)
+        pk = hip.ProvingKey.from_parts(**pk_o.parts())
+        ctx = hip.ProverContext(pk, r, one_stream=bool(i & 1))
+        assert r.domain_size == hip.get_domain_size(r)
+        assert hip.prove(ctx, wm) == expect, (nC, nIn)
+        ctx.close(); pk.close()
+
+
 def test_errors(hip, oracle, tmp_path):
     r, w = R.random_r1cs(12, 1, seed=2)
     pk_o, _ = oracle.keygen(r, seed=3)
