@@ -61,6 +61,7 @@ def main():
                          "what the latency-sized workloads need (one small proof alone is ~50 launches of latency-bound kernels)")
     ap.add_argument("--witness", choices=["resident", "host"], default="resident",
                     help="where the witness lives when the timed region starts (`value` is quoted on resident)")
+    ap.add_argument("--no-stage", action="store_true", help="host witness: plain zk_prove_submit instead of zk_prove_stage / zk_prove_submit_staged (double-buffered upload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary legs (host-witness rate, sharded legs, kernel sum)")
     ap.add_argument("--cpu-1t-logm", type=int, default=16, help="size of the one-thread CPU sample (a full 2^20 proof takes a minute on one core)")
@@ -138,6 +139,8 @@ def main():
         sharded = [ShardedProver(c, dist, torch.device("cuda", local_rank)) for c in ctxs] if (shard and not gloo) else None
         gather_buf = torch.empty((world, 640), dtype=torch.uint8) if (shard and gloo) else None
         acc_b, pending, state = [], [], {"t": {}}
+        use_stage = (witness == "host") and not shard and not args.no_stage
+        staged = [False] * len(ctxs)
 
         def finish(slot):
             """collect slot's proof; sharded: one all-gather of the 640-byte partials (device buffers), folded in rank order"""
@@ -163,7 +166,17 @@ def main():
                 if len(pending) == len(ctxs):
                     js = finish(pending.pop(0))
                 slot = i % len(ctxs)
-                if kb > 1:
+                if d_w is None and use_stage:
+                    # host witness, double-buffered upload: this context's NEXT witness was staged while its previous proof ran
+                    if staged[slot]:
+                        ctxs[slot].submit_staged()
+                    elif kb > 1:
+                        ctxs[slot].submit_batch(wmk, k=kb)
+                    else:
+                        ctxs[slot].submit(wm)
+                    ctxs[slot].stage(wmk.reshape(kb, -1, 4) if kb > 1 else wm)
+                    staged[slot] = True
+                elif kb > 1:
                     ctxs[slot].submit_batch(wmk, device_ptr=d_w.data_ptr() if d_w is not None else None, k=kb)
                 elif d_w is not None:
                     ctxs[slot].submit_resident(d_w.data_ptr())
@@ -223,8 +236,15 @@ def main():
                 h2 = run_leg(pk, r1cs, wm, shard, args.steps, args.warmup, other)      # same steps / warm-up as the headline leg
                 extras["%s_witness" % other] = {"value": round(h2["value"], 4), "unit": "proofs/s", "steps": args.steps,
                                                "ms_per_step": round(1e3 * h2["elapsed"] / args.steps, 3),
-                                               "note": ("witness handed over as a host buffer: its %.1f MB H2D copy is inside the timed region (PCIe-inclusive rate)" % (32 * (r1cs.V + 1) / 1e6))
+                                               "note": ("witness handed over as a host buffer: its copy into pinned memory and its %.1f MB H2D copy are inside the timed region (PCIe-inclusive rate); %s" % (32 * (r1cs.V + 1) / 1e6, "plain zk_prove_submit" if args.no_stage else "double-buffered: zk_prove_stage copies a context's next witness while its current proof runs"))
                                                        if other == "host" else "witness resident in HBM"}
+                if other == "host" and not args.no_stage:            # the same leg with a plain zk_prove_submit per proof
+                    args.no_stage = True
+                    try:
+                        h3 = run_leg(pk, r1cs, wm, shard, args.steps, args.warmup, other)
+                        extras["host_witness"]["plain_submit"] = {"value": round(h3["value"], 4), "ms_per_step": round(1e3 * h3["elapsed"] / args.steps, 3)}
+                    finally:
+                        args.no_stage = False
             except Exception as e:
                 extras["other_witness"] = {"error": repr(e)[:300]}
             if world > 1 and mode == "replicas":

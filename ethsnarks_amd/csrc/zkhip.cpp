@@ -525,6 +525,11 @@ struct zk_ctx {
     fe *d_w = nullptr, *d_a = nullptr, *d_b = nullptr, *d_c = nullptr, *d_t = nullptr;
     uint8_t *d_partials = nullptr;             // 640 bytes: the four partial sums in zk_partials layout, device copy
     fe *h_w = nullptr;                         // pinned staging for the witness
+    // double-buffered upload (zk_prove_stage): second device / pinned buffer pair, copy stream, allocated on first use
+    fe *d_w2 = nullptr, *h_w2 = nullptr;
+    hipStream_t s_copy = nullptr;
+    hipEvent_t ev_staged = nullptr;
+    uint32_t staged_k = 0; int staged_canonical = 0;
     fe *h_tail = nullptr;                      // pinned: h[m-1] for the degree check
     NttTables tab;
     MsmWork<G1> mA, mH, mL, mW; MsmWork<G2> mB;       // mW: sort-only, the shared witness-digit sort
@@ -537,6 +542,10 @@ struct zk_ctx {
         void *dev[] = {d_w, d_a, d_t, d_partials};           // d_b, d_c live inside d_a's allocation
         for (void *p : dev) if (p) hipFree(p);
         if (h_w) hipHostFree(h_w);
+        if (d_w2) hipFree(d_w2);
+        if (h_w2) hipHostFree(h_w2);
+        if (s_copy) hipStreamDestroy(s_copy);
+        if (ev_staged) hipEventDestroy(ev_staged);
         if (h_tail) hipHostFree(h_tail);
         cA.release(); cB.release(); cC.release();
         ntt_tables_free(tab);
@@ -759,12 +768,14 @@ static int enqueue_h_from_chains(zk_ctx *c, const fe *a, const fe *b, const fe *
 
 // witness: a host buffer (staged through pinned memory, the reference's pb.values), or -- resident != 0 -- a buffer that
 // already lives in this device's memory (the caller keeps it untouched until the proof is collected)
+// resident: 0 = host buffer, 1 = device buffer of the caller, 2 = staged earlier (zk_prove_stage): already in d_w
 static int upload_witness(zk_ctx *c, const uint64_t *witness, int canonical, int resident = 0) {
     const size_t n = (size_t)(c->V + 1) * c->cur_batch;          // the witnesses of a batch are contiguous
     if (!resident) memcpy(c->h_w, witness, 32 * n);
+    if (resident == 2) ZK_HIP(hipStreamWaitEvent(c->s_main, c->ev_staged, 0));
     ZK_HIP(hipEventRecord(c->ev_start, c->s_main));
-    if (resident) ZK_HIP(hipMemcpyAsync(c->d_w, witness, 32 * n, hipMemcpyDeviceToDevice, c->s_main));
-    else ZK_HIP(hipMemcpyAsync(c->d_w, c->h_w, 32 * n, hipMemcpyHostToDevice, c->s_main));
+    if (resident == 1) ZK_HIP(hipMemcpyAsync(c->d_w, witness, 32 * n, hipMemcpyDeviceToDevice, c->s_main));
+    else if (!resident) ZK_HIP(hipMemcpyAsync(c->d_w, c->h_w, 32 * n, hipMemcpyHostToDevice, c->s_main));
     if (canonical) ZK_LAUNCH(k_to_mont, zk_div_up(n, 256), 256, c->s_main, c->d_w, (uint32_t)n);
     ZK_HIP(hipEventRecord(c->ev_w, c->s_main));
     return ZK_OK;
@@ -867,6 +878,36 @@ static int prove_partial_impl(zk_ctx *c, const uint64_t *witness, int canonical,
 // asynchronous form: enqueue a proof and return; collect later (lets two contexts keep the GPU full)
 extern "C" int zk_prove_submit(zk_ctx *ctx, const uint64_t *witness, int canonical) { return prove_submit_impl(ctx, witness, canonical); }
 extern "C" int zk_prove_submit_resident(zk_ctx *ctx, const void *d_witness, int canonical) { return prove_submit_impl(ctx, (const uint64_t *)d_witness, canonical, 1); }
+// ---- double-buffered upload: the NEXT witness (k of them, contiguous) goes to the device on a copy stream while a
+// proof may still be in flight on this context; zk_prove_submit_staged then starts it with no upload on its critical path
+extern "C" int zk_prove_stage(zk_ctx *c, const uint64_t *witnesses, uint32_t k, int canonical) {
+    if (!c || !witnesses) return fail(ZK_ERR_ARG, "null argument");
+    if (!k || k > c->max_batch) return fail(ZK_ERR_ARG, "batch size exceeds zk_config.max_batch of this context");
+    if (c->staged_k) return fail(ZK_ERR_ARG, "a witness is already staged on this context (submit it first)");
+    ZK_TRY(use_device(c->device));
+    const size_t cap = 32 * (size_t)(c->V + 1) * c->max_batch, n = 32 * (size_t)(c->V + 1) * k;
+    if (!c->d_w2) {
+        ZK_HIP(hipMalloc(&c->d_w2, cap));
+        ZK_HIP(hipHostMalloc(&c->h_w2, cap, hipHostMallocDefault));
+        ZK_HIP(hipStreamCreateWithFlags(&c->s_copy, hipStreamNonBlocking));
+        ZK_HIP(hipEventCreateWithFlags(&c->ev_staged, hipEventDisableTiming));
+    }
+    ZK_HIP(hipStreamSynchronize(c->s_copy));                    // (the previous staged copy out of h_w2 has long finished; cheap)
+    memcpy(c->h_w2, witnesses, n);
+    ZK_HIP(hipMemcpyAsync(c->d_w2, c->h_w2, n, hipMemcpyHostToDevice, c->s_copy));
+    ZK_HIP(hipEventRecord(c->ev_staged, c->s_copy));
+    c->staged_k = k; c->staged_canonical = canonical;
+    return ZK_OK;
+}
+extern "C" int zk_prove_submit_staged(zk_ctx *c) {
+    if (!c) return fail(ZK_ERR_ARG, "null argument");
+    if (!c->staged_k) return fail(ZK_ERR_ARG, "no staged witness on this context (zk_prove_stage first)");
+    if (c->in_flight) return fail(ZK_ERR_ARG, "a proof is already in flight on this context (collect it first)");
+    std::swap(c->d_w, c->d_w2);                                 // the collected proof no longer reads the old buffer
+    const uint32_t k = c->staged_k;
+    c->staged_k = 0;
+    return prove_submit_impl(c, (const uint64_t *)c->d_w, c->staged_canonical, 2, k);
+}
 // ---- SURVEY 8(e) option 2: the transform chains of the witness map on different ranks (ethsnarks_amd/sharded.py drives it)
 extern "C" int zk_chain_submit(zk_ctx *c, const uint64_t *witness, int canonical, int which) {
     if (!c || !witness || which < 0 || which > 2) return fail(ZK_ERR_ARG, "bad argument");

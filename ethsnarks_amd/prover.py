@@ -63,7 +63,7 @@ EXPORTS = [
     "zk_prove_batch", "zk_prove_batch_submit", "zk_prove_batch_submit_resident", "zk_prove_batch_collect",
     "zk_wplan_create", "zk_wplan_solve", "zk_wplan_free", "zk_dev_alloc", "zk_dev_free", "zk_dev_upload", "zk_dev_download",
     "zk_chain_submit", "zk_chain_device", "zk_h_from_chains_submit", "zk_h_device", "zk_chain_wait", "zk_prove_submit_with_h",
-    "zk_prove_submit_resident", "zk_ctx_info", "zk_ctx_partials_device", "zk_prove_collect_device", "zk_prove_combine_device", "zk_launch_count", "zk_profile_begin", "zk_profile_end", "zk_device_info",
+    "zk_prove_submit_resident", "zk_prove_stage", "zk_prove_submit_staged", "zk_ctx_info", "zk_ctx_partials_device", "zk_prove_collect_device", "zk_prove_combine_device", "zk_launch_count", "zk_profile_begin", "zk_profile_end", "zk_device_info",
     "zk_verify",
     "zk_ntt", "zk_witness_map", "zk_msm_g1", "zk_msm_g2", "zk_field_mul", "zk_fr_convert",
 ]
@@ -380,6 +380,18 @@ class ProverContext:
         """zk_prove_submit_resident: the witness already lives in this device's memory (device_ptr = integer address of
         (V + 1) x 32 bytes); the caller keeps that buffer untouched until collect()"""
         _check(_lib.zk_prove_submit_resident(self._h, C.c_void_p(device_ptr), int(canonical)))
+
+    def stage(self, witnesses, canonical=False):
+        """zk_prove_stage: copy the NEXT witness (or k of them, shape (k, V + 1, 4)) to the device while a proof may still be
+        in flight on this context; returns k"""
+        w = np.ascontiguousarray(witnesses, dtype=np.uint64)
+        k = 1 if w.ndim == 2 else int(w.shape[0])
+        _check(_lib.zk_prove_stage(self._h, _p64(w), C.c_uint32(k), int(canonical)))
+        return k
+
+    def submit_staged(self):
+        """zk_prove_submit_staged: start the staged proof (no upload on its critical path); collect() / collect_batch(k) as usual"""
+        _check(_lib.zk_prove_submit_staged(self._h))
 
     def info(self):
         """window bits / windows / buckets per query, shared-sort flags, domain size (zk_ctx_info)"""

@@ -203,6 +203,11 @@ int zk_prove_submit_with_h(zk_ctx *ctx, const uint64_t *witness, int canonical, 
 /* zk_prove_submit for a witness that is already resident in the context's device memory (d_witness = device
  * pointer to (V + 1) x 32 bytes, e.g. written by a GPU witness generator); it must stay untouched until collected */
 int zk_prove_submit_resident(zk_ctx *ctx, const void *d_witness, int canonical);
+/* double-buffered upload: zk_prove_stage copies the NEXT witness (k of them, k <= zk_config.max_batch) to the
+ * device on a copy stream, also while a proof is in flight on this context; zk_prove_submit_staged starts that proof with no
+ * upload on its critical path (collect as usual: zk_prove_collect / zk_prove_batch_collect).  One staged witness per context. */
+int zk_prove_stage(zk_ctx *ctx, const uint64_t *witnesses, uint32_t k, int canonical);
+int zk_prove_submit_staged(zk_ctx *ctx);
 /* info[3q .. 3q+2] = {window bits c, windows W, buckets 2^(c-1)} of query q = A, B, H, L; info[12..14] = the A-, B-, L-query
  * ride the shared witness sort; info[15] = domain size m */
 int zk_ctx_info(const zk_ctx *ctx, uint32_t info[16]);

@@ -110,6 +110,29 @@ def test_prove_shape_sweep(zk, oracle):
         ctx.close(); pk.close()
 
 
+def test_staged_upload(zk, oracle):
+    """zk_prove_stage / zk_prove_submit_staged (double-buffered upload): same proofs, buffers swap cleanly"""
+    r, w = R.random_r1cs(40, 1, seed=3)
+    _, w2 = R.random_r1cs(40, 1, seed=3, witness_seed=9)
+    wa, wb = F.fr_to_mont(w), F.fr_to_mont(w2)
+    pk_o, _ = oracle.keygen(r, seed=2)
+    ea, eb = oracle.prove(pk_o, r, wa)[0], oracle.prove(pk_o, r, wb)[0]
+    pk = zk.ProvingKey.from_parts(**pk_o.parts())
+    c = zk.ProverContext(pk, r)
+    with pytest.raises(zk.ZkError):
+        c.submit_staged()
+    c.submit(wa); c.stage(wb)
+    with pytest.raises(zk.ZkError):
+        c.submit_staged()                                                    # a is in flight
+    part, _ = c.collect()
+    assert zk.proof_to_json(c.prove_combine(part), wa[1:2]) == ea
+    c.submit_staged()
+    part, _ = c.collect()
+    assert zk.proof_to_json(c.prove_combine(part), wb[1:2]) == eb
+    assert zk.prove(c, wa) == ea
+    c.close(); pk.close()
+
+
 def test_prove_chain_long_rows_and_sharding(zk, oracle, tmp_path):
     r, w = R.synthetic_chain(254, 1)                    # last row: 510 terms -> long-row path
     wm = F.fr_to_mont(w)

@@ -349,6 +349,35 @@ def test_config2_chain_2pow18_gpu_keygen(hip, oracle, tmp_path):
     assert hip.prove(ctx, wm) == expect
 
 
+def test_staged_upload_double_buffering(hip, oracle):
+    """zk_prove_stage / zk_prove_submit_staged: the next witness is copied while a proof is in flight; proofs unchanged"""
+    r, w = R.random_r1cs(900, 2, seed=41)
+    r2, w2 = R.random_r1cs(900, 2, seed=41, witness_seed=7)
+    wa, wb = F.fr_to_mont(w), F.fr_to_mont(w2)
+    pk_o, _ = oracle.keygen(r, seed=6)
+    ea, eb = oracle.prove(pk_o, r, wa)[0], oracle.prove(pk_o, r, wb)[0]
+    pk = hip.ProvingKey.from_parts(**pk_o.parts())
+    c = hip.ProverContext(pk, r, max_batch=2)
+    with pytest.raises(hip.ZkError):
+        c.submit_staged()                                                    # nothing staged
+    c.submit(wa)
+    c.stage(wb)                                                              # while proof a is in flight
+    with pytest.raises(hip.ZkError):
+        c.stage(wb)                                                          # one staged witness per context
+    with pytest.raises(hip.ZkError):
+        c.submit_staged()                                                    # a is still in flight
+    part, _ = c.collect()
+    assert hip.proof_to_json(c.prove_combine(part), wa[1:3]) == ea
+    c.submit_staged()
+    c.stage(np.stack([wa, wb]))                                              # next: a batch of two, staged while b runs
+    part, _ = c.collect()
+    assert hip.proof_to_json(c.prove_combine(part), wb[1:3]) == eb
+    c.submit_staged()
+    parts, _ = c.collect_batch(2)
+    assert [hip.proof_to_json(c.prove_combine(parts[i:i + 1]), x[1:3]) for i, x in enumerate((wa, wb))] == [ea, eb]
+    assert hip.prove(c, wa) == ea                                            # ordinary submit after the buffers were swapped
+
+
 def test_async_submit_collect_two_contexts(hip, oracle):
     r, w = R.synthetic_chain((1 << 12) - 2, 1)
     wm = F.fr_to_mont(w)
