@@ -30,6 +30,21 @@ __global__ void __launch_bounds__(256, WPS) k_dot2(fe *io, int iters) {         
     for (int i = 0; i < iters; i++) { a = Fq::lmul2(a, b, c, d); c = Fq::lmul2(c, d, a, b); }
     io[t] = Fq::ladd(a, c);
 }
+template <int WPS>
+__global__ void __launch_bounds__(256, WPS) k_fq2mul(fe *io, int iters) {        // Fq2 product chain: two independent dot products per product
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    fe2 x, y; x.c0 = io[t]; x.c1 = io[t + gridDim.x * blockDim.x]; y.c0 = Fq::ladd(x.c0, x.c1); y.c1 = Fq::ladd(x.c1, x.c1);
+    for (int i = 0; i < iters; i++) { x = Fq2::lmul(x, y); y = Fq2::lmul(y, x); }
+    io[t] = Fq::ladd(Fq::ladd(x.c0, x.c1), Fq::ladd(y.c0, y.c1));
+}
+template <int WPS>
+__global__ void __launch_bounds__(256, WPS) k_dot2x2(fe *io, int iters) {        // two independent lmul2 chains per thread
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    fe a = io[t], b = io[t + gridDim.x * blockDim.x], c = Fq::ladd(a, b), d = Fq::ladd(b, b);
+    fe e = Fq::ladd(a, c), f = Fq::ladd(b, d), g = Fq::ladd(c, d), h = Fq::ladd(d, d);
+    for (int i = 0; i < iters; i++) { a = Fq::lmul2(a, b, c, d); e = Fq::lmul2(e, f, g, h); c = Fq::lmul2(c, d, a, b); g = Fq::lmul2(g, h, e, f); }
+    io[t] = Fq::ladd(Fq::ladd(a, c), Fq::ladd(e, g));
+}
 template <class C, int WPS>
 __global__ void __launch_bounds__(64, WPS) k_madd(const typename C::Affine *pts, typename C::XYZZ *out, int iters, uint32_t npts) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -69,6 +84,8 @@ int main(int argc, char **argv) {
     RUN("mul chain", k_mul1, 1, 2) RUN("mul chain", k_mul1, 2, 2) RUN("mul chain", k_mul1, 4, 2) RUN("mul chain", k_mul1, 8, 2)
     RUN("mul 2-ilp", k_mul2, 1, 4) RUN("mul 2-ilp", k_mul2, 2, 4) RUN("mul 2-ilp", k_mul2, 4, 4)
     RUN("dot2 chain", k_dot2, 2, 2) RUN("dot2 chain", k_dot2, 4, 2)
+    RUN("dot2 2-ilp", k_dot2x2, 2, 4) RUN("dot2 2-ilp", k_dot2x2, 4, 4)
+    RUN("Fq2 mul chain", k_fq2mul, 2, 4) RUN("Fq2 mul chain", k_fq2mul, 4, 4)
     {   // mixed-addition chains with gathered operands (table of 2^16 points: L2-resident)
         const uint32_t npts = 1u << 16;
         G2::Affine *pts; hipMalloc(&pts, sizeof(G2::Affine) * npts);
