@@ -324,6 +324,23 @@ struct Field {
     static ZK_HD fe lsqr(const fe &a) { return lmul(a, a); }
     static ZK_HD fe ldbl(const fe &a) { return ladd(a, a); }
     static ZK_HD fe lneg(const fe &a) { return lsub(zero(), a); }
+    // -a as an OPERAND OF A PRODUCT: 2p - a in (0, 2p], eight subtractions and no fold.  2p itself is outside the loose domain but
+    // the product bounds hold for operands <= 2p ((4p^2 + Rp)/R < 2p, (8p^2 + Rp)/R < 2.51p, (16p^2 + Rp)/R < 4.03p), so the value
+    // may feed lmul / lmul2 / lmul4 and nothing else (never compared, stored or added)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZK_NO_ASM)
+    static __device__ __forceinline__ fe lneg_op(const fe &a) {
+        fe pp, d;
+#pragma unroll
+        for (int i = 0; i < 8; i++) pp.l[i] = (P::p(i) << 1) | (i ? P::p(i - 1) >> 31 : 0u);
+        fips::sub8(d.l, pp.l, a.l);
+        return d;
+    }
+#else
+    static ZK_HD fe lneg_op(const fe &a) { return lneg(a); }
+#endif
+    // the negated Y operand of the curve formulas' dot products: the G1 kernels sit at their register limit and keep the folded
+    // form (the unfolded one costs them a spill), Fq2 takes the cheap one
+    static ZK_HD fe lneg_yop(const fe &a) { return lneg(a); }
     // quad helpers (Curve::*_q): lane ql of a 4-lane group picks its operand; qbcast<S> hands lane S's value to all four
     static ZK_HD fe qsel(uint32_t ql, const fe &a, const fe &b, const fe &c, const fe &d) {
         fe r; const bool odd = ql & 1u, hi = ql & 2u;
@@ -397,19 +414,21 @@ struct Fq2 {
     static ZK_HD fe2 ladd(const fe2 &a, const fe2 &b) { fe2 r; r.c0 = Fq::ladd(a.c0, b.c0); r.c1 = Fq::ladd(a.c1, b.c1); return r; }
     static ZK_HD fe2 lsub(const fe2 &a, const fe2 &b) { fe2 r; r.c0 = Fq::lsub(a.c0, b.c0); r.c1 = Fq::lsub(a.c1, b.c1); return r; }
     static ZK_HD fe2 lneg(const fe2 &a) { fe2 r; r.c0 = Fq::lneg(a.c0); r.c1 = Fq::lneg(a.c1); return r; }
+    static ZK_HD fe2 lneg_op(const fe2 &a) { fe2 r; r.c0 = Fq::lneg_op(a.c0); r.c1 = Fq::lneg_op(a.c1); return r; }   // product operand only (Field::lneg_op)
+    static ZK_HD fe2 lneg_yop(const fe2 &a) { return lneg_op(a); }
     static ZK_HD fe2 ldbl(const fe2 &a) { return ladd(a, a); }
     // schoolbook with one reduction per component (Field::lmul2): 4 x 64 + 2 x 72 multiplies and two folds, against
     // Karatsuba's 3 x 136 multiplies plus five modular additions -- fewer VALU issue slots on gfx950
     static ZK_HD fe2 lmul(const fe2 &a, const fe2 &b) {
         fe2 r;
-        r.c0 = Fq::lmul2(a.c0, b.c0, a.c1, Fq::lneg(b.c1));
+        r.c0 = Fq::lmul2(a.c0, b.c0, a.c1, Fq::lneg_op(b.c1));
         r.c1 = Fq::lmul2(a.c0, b.c1, a.c1, b.c0);
         return r;
     }
     // a*b + c*d in Fq2, one reduction per component
     static ZK_HD fe2 lmul2(const fe2 &a, const fe2 &b, const fe2 &c, const fe2 &d) {
         fe2 r;
-        r.c0 = Fq::lmul4(a.c0, b.c0, a.c1, Fq::lneg(b.c1), c.c0, d.c0, c.c1, Fq::lneg(d.c1));
+        r.c0 = Fq::lmul4(a.c0, b.c0, a.c1, Fq::lneg_op(b.c1), c.c0, d.c0, c.c1, Fq::lneg_op(d.c1));
         r.c1 = Fq::lmul4(a.c0, b.c1, a.c1, b.c0, c.c0, d.c1, c.c1, d.c0);
         return r;
     }
@@ -457,7 +476,7 @@ struct Curve {
         E xx = F::lsqr(p.x), M = F::ladd(F::ldbl(xx), xx);
         XYZZ r;
         r.X = F::lsub(F::lsqr(M), F::ldbl(S));
-        r.Y = F::lmul2(M, F::lsub(S, r.X), W, F::lneg(p.y));           // M (S - X3) - W y: one reduction
+        r.Y = F::lmul2(M, F::lsub(S, r.X), W, F::lneg_yop(p.y));           // M (S - X3) - W y: one reduction
         r.ZZ = V; r.ZZZ = W;
         return r;
     }
@@ -468,7 +487,7 @@ struct Curve {
         E xx = F::lsqr(p.X), M = F::ladd(F::ldbl(xx), xx);
         XYZZ r;
         r.X = F::lsub(F::lsqr(M), F::ldbl(S));
-        r.Y = F::lmul2(M, F::lsub(S, r.X), W, F::lneg(p.Y));
+        r.Y = F::lmul2(M, F::lsub(S, r.X), W, F::lneg_yop(p.Y));
         r.ZZ = F::lmul(V, p.ZZ); r.ZZZ = F::lmul(W, p.ZZZ);
         return r;
     }
@@ -488,7 +507,7 @@ struct Curve {
         const E Q = F::lmul(p.X, PP), PPP = F::lmul(Pd, PP);
         r.ZZZ = F::lmul(p.ZZZ, PPP);
         r.X = F::lsub(F::lsub(F::lsqr(R), PPP), F::ldbl(Q));
-        r.Y = F::lmul2(R, F::lsub(Q, r.X), F::lneg(p.Y), PPP);        // R (Q - X3) - Y1 PPP: one reduction
+        r.Y = F::lmul2(R, F::lsub(Q, r.X), F::lneg_yop(p.Y), PPP);        // R (Q - X3) - Y1 PPP: one reduction
         return r;
     }
     // p + q (add-2008-s)
@@ -505,7 +524,7 @@ struct Curve {
         E PP = F::lsqr(Pd), PPP = F::lmul(Pd, PP), Q = F::lmul(U1, PP);
         XYZZ r;
         r.X = F::lsub(F::lsub(F::lsqr(R), PPP), F::ldbl(Q));
-        r.Y = F::lmul2(R, F::lsub(Q, r.X), F::lneg(S1), PPP);
+        r.Y = F::lmul2(R, F::lsub(Q, r.X), F::lneg_yop(S1), PPP);
         r.ZZ = F::lmul(F::lmul(p.ZZ, q.ZZ), PP); r.ZZZ = F::lmul(F::lmul(p.ZZZ, q.ZZZ), PPP);
         return r;
     }
