@@ -128,6 +128,8 @@ def main():
 
     from ethsnarks_amd.sharded import ShardedProver
 
+    all_acc_b = []          # every B-query accumulation this process launched (warm-ups and secondary legs too): what a profiler averages
+
     def run_leg(pk, r1cs, wm, shard, steps, warmup, witness):
         """`warmup` untimed + `steps` timed proofs in one parallelisation"""
         kb = max(1, args.batch) if not shard else 1
@@ -158,6 +160,7 @@ def main():
                 proof = ctxs[slot].prove_combine(part)
             state["t"] = tm
             acc_b.append(tm["acc_b"])
+            all_acc_b.append(tm["acc_b"])
             return P.proof_to_json(proof, wm[1:1 + r1cs.nIn])
 
         def run(nsteps):
@@ -209,6 +212,7 @@ def main():
             P.profile_begin()
             ctxs[0].submit_resident(d_w.data_ptr()) if d_w is not None else ctxs[0].submit(wm)
             _, t_alone = ctxs[0].collect()
+            all_acc_b.append(t_alone["acc_b"])
             s_ms, n_l, per = P.profile_end()
             top = sorted(per.items(), key=lambda kv: -kv[1][1])[:6]
             ksum = {"kernel_ms_sum_one_proof_alone": round(s_ms, 3), "launches": n_l, "acc_b_ms_alone": round(t_alone["acc_b"], 4),
@@ -361,6 +365,9 @@ def main():
         watchdog.cancel()
     if rank == 0:
         out.update(extras)
+        if all_acc_b and not shard:
+            out["roofline"]["all_launches"] = {"launches": len(all_acc_b), "avg_launch_ms": round(float(np.mean(all_acc_b)), 4),
+                                               "note": "every launch of the kernel in this process (warm-ups, secondary legs and the single-proof pass included): the average a `rocprofv3 --kernel-trace --stats` of this command reports"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], out["parity_vs_oracle"] = cpu_baseline(args, P, R, F, pk, r1cs, wm, js, logm, local_rank)
     if dist is not None:
