@@ -268,6 +268,68 @@ inline std::string prove_const(ProverContextT &context, const ProtoboardT &pb) {
 }  // namespace detail
 inline std::string prove(ProverContextT &context, ProtoboardT &pb) { return detail::prove_const(context, pb); }
 
+// Throughput form of prove() (no reference counterpart: the reference's ProverContext is one synchronous prover per thread,
+// hpp:279-291).  N contexts of ONE key and ONE constraint system stay in flight on the GPU; submit() hands over the values of a
+// protoboard of that system, next() returns the proofs in submission order, each the JSON prove() would return.  A context that
+// is still proving takes its next witness ahead (zk_prove_stage: copied to the device under the running proof), so up to 2 N
+// submissions are accepted before next() has to be called.  Single-threaded like the contexts themselves.
+class ProverPipeline {
+ public:
+    ProverPipeline(const ProvingKeyT &pk, const ProtoboardT &pb, unsigned contexts = 3, const libsnark::Config &config = libsnark::Config())
+        : nIn_((uint32_t)pb.constraint_system.num_inputs()), n_values_(pb.values.size()) {
+        const detail::FlatSystem f(pb.constraint_system);
+        const zk_csr a = f.a(), b = f.b(), c = f.c();
+        zk_config cfg{config.multi_exp_c, hip_device(), 0, 1, 1, ZK_SCHED_OVERLAP};
+        for (unsigned i = 0; i < (contexts ? contexts : 1); i++) {
+            zk_ctx *h = nullptr;
+            zk_check(zk_ctx_create(pk.get(), &a, &b, &c, f.nC, f.nIn, f.V, &cfg, &h));
+            slots_.emplace_back();
+            slots_.back().ctx.reset(h, zk_ctx_destroy);
+        }
+    }
+    size_t pending() const { return submitted_ - collected_; }
+    bool full() const { return pending() >= 2 * slots_.size(); }
+    void submit(const ProtoboardT &pb) {
+        if (pb.values.size() != n_values_) throw std::invalid_argument("ProverPipeline: protoboard of another constraint system");
+        if (full()) throw std::runtime_error("ProverPipeline: full (call next() first)");
+        Slot &s = slots_[submitted_ % slots_.size()];
+        const detail::Witness w(pb);
+        std::vector<uint64_t> inputs(w.ptr + 4, w.ptr + 4 + 4 * (size_t)nIn_);
+        if (!s.busy) {
+            zk_check(zk_prove_submit(s.ctx.get(), w.ptr, w.canonical));
+            s.busy = true; s.inputs = std::move(inputs); s.canonical = w.canonical;
+        } else {                                                   // second round: this context's next witness goes ahead of its turn
+            zk_check(zk_prove_stage(s.ctx.get(), w.ptr, 1, w.canonical));
+            s.staged = true; s.staged_inputs = std::move(inputs); s.staged_canonical = w.canonical;
+        }
+        submitted_++;
+    }
+    std::string next() {
+        if (!pending()) throw std::runtime_error("ProverPipeline: nothing submitted");
+        Slot &s = slots_[collected_ % slots_.size()];
+        zk_partials part; zk_proof proof;
+        zk_check(zk_prove_collect(s.ctx.get(), &part, nullptr));
+        zk_check(zk_prove_combine(s.ctx.get(), &part, 1, &proof));
+        size_t len = 0;
+        zk_proof_to_json(&proof, s.inputs.data(), nIn_, s.canonical, nullptr, 0, &len);
+        std::string out(len + 1, '\0');
+        zk_check(zk_proof_to_json(&proof, s.inputs.data(), nIn_, s.canonical, &out[0], out.size(), &len));
+        out.resize(len);
+        s.busy = false;
+        if (s.staged) {
+            zk_check(zk_prove_submit_staged(s.ctx.get()));
+            s.busy = true; s.staged = false; s.inputs = std::move(s.staged_inputs); s.canonical = s.staged_canonical;
+        }
+        collected_++;
+        return out;
+    }
+ private:
+    struct Slot { std::shared_ptr<zk_ctx> ctx; bool busy = false, staged = false; std::vector<uint64_t> inputs, staged_inputs; int canonical = 0, staged_canonical = 0; };
+    std::vector<Slot> slots_;
+    uint32_t nIn_; size_t n_values_;
+    size_t submitted_ = 0, collected_ = 0;
+};
+
 namespace detail {
 inline std::string prove_from_pb_const(const ProtoboardT &pb, const char *pk_raw) {
     ProvingKeyT pk = load_proving_key(pk_raw);

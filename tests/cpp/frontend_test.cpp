@@ -9,6 +9,7 @@
 //   frontend_test prove <pk.raw> <vk.json> <proof.json>   keygen + prove + verify of that circuit through the adapter (GPU)
 //   frontend_test roundtrip                            stub_test_proof_verify on the MiMC hash circuit (GPU)
 //   frontend_test context <pk.raw> <vk.json>           the ProverContextT caller sequence of SURVEY section 3 (GPU)
+//   frontend_test pipeline <pk.raw> <vk.json>          ProverPipeline: proofs of several witnesses kept in flight, in order (GPU)
 //   frontend_test verify_cli <vk.json> <proof.json>    stub_main_verify (host only): exit code 0 / 1 / 2 like the reference's
 #include "ethsnarks_hip/stubs.hpp"
 #include "ethsnarks_hip/gadgets.hpp"
@@ -167,6 +168,41 @@ int main(int argc, char **argv) {
             std::ifstream vf(argv[3], std::ios::binary);
             const std::string vk((std::istreambuf_iterator<char>(vf)), std::istreambuf_iterator<char>());
             const bool ok = ctx.domain->m == 1024 && stub_verify(vk.c_str(), json.c_str()) && prove(ctx, pb) == json;
+            std::cout << (ok ? "VERIFIED" : "REJECTED") << std::endl;
+            return ok ? 0 : 1;
+        }
+        if (mode == "pipeline" && argc == 4) {                // ProverPipeline: 7 witnesses of one circuit through 2 contexts, in order
+            ProtoboardT pb;
+            const VariableT m_0 = make_variable(pb, FieldT(ITEM_A), "m_0"), m_1 = make_variable(pb, FieldT(ITEM_B), "m_1");
+            pb.set_input_sizes(2);
+            const VariableT iv = make_variable(pb, FieldT("918403109389145570117360101535982733651217667914747213867238065296420114726"), "iv");
+            MiMC_e7_hash_gadget the_gadget(pb, iv, {m_0, m_1}, "gadget");
+            the_gadget.generate_r1cs_witness();
+            the_gadget.generate_r1cs_constraints();
+            if (stub_genkeys_from_pb(pb, argv[2], argv[3]) != 0) return 1;
+            ProvingKeyT pk = load_proving_key(argv[2]);
+            ProverContextT ctx(pk);
+            ProverPipeline pipe(pk, pb, 2);
+            std::vector<std::string> expect, got;
+            bool ok = true;
+            for (int round = 0; round < 2; round++) {
+                const int n = round ? 3 : 4;                      // 4 = 2 running + 2 staged (full), then 3
+                for (int i = 0; i < n; i++) {
+                    pb.val(m_0) = FieldT(ITEM_A) + FieldT(1000 * round + i);
+                    the_gadget.generate_r1cs_witness();
+                    ok = ok && pb.is_satisfied();
+                    expect.push_back(prove(ctx, pb));
+                    pipe.submit(pb);
+                }
+                if (!round) {
+                    ok = ok && pipe.full();
+                    try { pipe.submit(pb); ok = false; } catch (const std::runtime_error &) {}
+                }
+                while (pipe.pending()) got.push_back(pipe.next());
+            }
+            std::ifstream vf(argv[3], std::ios::binary);
+            const std::string vk((std::istreambuf_iterator<char>(vf)), std::istreambuf_iterator<char>());
+            ok = ok && got == expect && got.size() == 7 && got[0] != got[1] && stub_verify(vk.c_str(), got[6].c_str());
             std::cout << (ok ? "VERIFIED" : "REJECTED") << std::endl;
             return ok ? 0 : 1;
         }

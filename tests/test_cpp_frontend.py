@@ -100,6 +100,14 @@ def test_adapter_prover_context_call_sequence(exe, tmp_path):
     assert p.returncode == 0 and p.stdout.strip() == "VERIFIED", p.stdout + p.stderr
 
 
+@pytest.mark.gpu
+def test_adapter_prover_pipeline(exe, tmp_path):
+    """ProverPipeline: seven witnesses of the MiMC hash circuit through two contexts (running + staged), proofs in submission
+    order and equal to prove()'s, `full()` honoured"""
+    p = subprocess.run([exe, "pipeline", str(tmp_path / "pk.raw"), str(tmp_path / "vk.json")], capture_output=True, text=True)
+    assert p.returncode == 0 and p.stdout.strip() == "VERIFIED", p.stdout + p.stderr
+
+
 @pytest.fixture(scope="module")
 def exe_libsnark_branch(tmp_path_factory):
     """the adapter's `libsnark is on the include path` branch, compiled against the API double of tests/cpp/libsnark_api_double"""
