@@ -1,3 +1,4 @@
+"""dev tool: host-side cost of zk_prove_submit / zk_prove_collect at 2^20 with three contexts in flight (is the host or the GPU the limit?)"""
 import os, sys, time
 sys.path[:0] = [os.getcwd()]
 import torch; torch.zeros(1).cuda()
