@@ -33,17 +33,67 @@ inline thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
 struct uint2 { unsigned x, y; };
 
 namespace zk_emul {
-// Workgroups that use __syncthreads() run as cooperative fibers (ucontext) inside the calling OS thread:
-// a fiber runs until its next barrier, then the scheduler resumes the next one; one sweep over all fibers
-// completes the barrier.  (Real threads cost a context switch per thread per barrier: ~100x slower.)
+// Workgroups that use __syncthreads() run as cooperative fibers inside the calling OS thread: a fiber runs until its next
+// barrier, then the scheduler resumes the next one; one sweep over all fibers completes the barrier.  (Real threads cost a
+// context switch per thread per barrier: ~100x slower.)  On x86-64 the switch is six pushes and pops (swapcontext makes a
+// signal-mask system call per switch, which dominated the CPU test time); elsewhere ucontext.
+#if defined(__x86_64__)
+extern "C" void zk_emul_switch(void **save_sp, void *new_sp);
+asm(R"(
+    .text
+    .weak zk_emul_switch
+    .type zk_emul_switch,@function
+zk_emul_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+    .size zk_emul_switch, .-zk_emul_switch
+)");
+struct Fiber { void *sp; bool done; };
+inline void *g_sched_sp = nullptr;
+#else
 struct Fiber { ucontext_t ctx; bool done; };
 inline ucontext_t g_sched;
+#endif
 inline Fiber *g_cur = nullptr;
 inline std::function<void()> *g_body = nullptr;
 inline std::vector<Fiber> g_fibers;
 inline std::vector<char> g_stacks;
 constexpr size_t FIBER_STACK = 256 * 1024;
+#if defined(__x86_64__)
+inline void yield_to_scheduler() { zk_emul_switch(&g_cur->sp, g_sched_sp); }
+inline void trampoline() { (*g_body)(); g_cur->done = true; yield_to_scheduler(); __builtin_trap(); }
+inline void fiber_init(Fiber &f, char *stack) {
+    uintptr_t top = ((uintptr_t)stack + FIBER_STACK) & ~(uintptr_t)15;
+    void **sp = (void **)(top - 64);                      // 6 saved registers, the entry address, a null return address
+    for (int i = 0; i < 6; i++) sp[i] = nullptr;
+    sp[6] = (void *)&trampoline; sp[7] = nullptr;         // after `ret`: rsp = top - 8, as after a call
+    f.sp = sp; f.done = false;
+}
+inline void fiber_resume(Fiber &f) { zk_emul_switch(&g_sched_sp, f.sp); }
+#else
+inline void yield_to_scheduler() { swapcontext(&g_cur->ctx, &g_sched); }
 inline void trampoline() { (*g_body)(); g_cur->done = true; }
+inline void fiber_init(Fiber &f, char *stack) {
+    getcontext(&f.ctx);
+    f.ctx.uc_stack.ss_sp = stack; f.ctx.uc_stack.ss_size = FIBER_STACK; f.ctx.uc_link = &g_sched;
+    f.done = false;
+    makecontext(&f.ctx, (void (*)())trampoline, 0);
+}
+inline void fiber_resume(Fiber &f) { swapcontext(&g_sched, &f.ctx); }
+#endif
 
 template <class Body>
 void launch(bool needs_sync, dim3 grid, dim3 block, Body body) {
@@ -62,15 +112,7 @@ void launch(bool needs_sync, dim3 grid, dim3 block, Body body) {
     if (g_stacks.size() < (size_t)block.x * FIBER_STACK) g_stacks.resize((size_t)block.x * FIBER_STACK);
     for (unsigned bxy = 0; bxy < grid.x * grid.y; bxy++) {
         const unsigned bx = bxy % grid.x, by = bxy / grid.x;
-        for (unsigned tx = 0; tx < block.x; tx++) {
-            Fiber &f = g_fibers[tx];
-            getcontext(&f.ctx);
-            f.ctx.uc_stack.ss_sp = g_stacks.data() + (size_t)tx * FIBER_STACK;
-            f.ctx.uc_stack.ss_size = FIBER_STACK;
-            f.ctx.uc_link = &g_sched;
-            f.done = false;
-            makecontext(&f.ctx, (void (*)())trampoline, 0);
-        }
+        for (unsigned tx = 0; tx < block.x; tx++) fiber_init(g_fibers[tx], g_stacks.data() + (size_t)tx * FIBER_STACK);
         bool any = true;
         while (any) {
             any = false;
@@ -79,7 +121,7 @@ void launch(bool needs_sync, dim3 grid, dim3 block, Body body) {
                 if (f.done) continue;
                 threadIdx = dim3(tx); blockIdx = dim3(bx, by); blockDim = block; gridDim = grid;
                 g_cur = &f;
-                swapcontext(&g_sched, &f.ctx);
+                fiber_resume(f);
                 if (!f.done) any = true;
             }
         }
@@ -88,7 +130,7 @@ void launch(bool needs_sync, dim3 grid, dim3 block, Body body) {
 }
 }  // namespace zk_emul
 
-inline void __syncthreads() { if (zk_emul::g_cur) swapcontext(&zk_emul::g_cur->ctx, &zk_emul::g_sched); }
+inline void __syncthreads() { if (zk_emul::g_cur) zk_emul::yield_to_scheduler(); }
 inline unsigned atomicAdd(unsigned *p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 inline unsigned atomicMax(unsigned *p, unsigned v) {
