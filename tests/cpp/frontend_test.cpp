@@ -10,6 +10,7 @@
 //   frontend_test roundtrip                            stub_test_proof_verify on the MiMC hash circuit (GPU)
 //   frontend_test context <pk.raw> <vk.json>           the ProverContextT caller sequence of SURVEY section 3 (GPU)
 //   frontend_test pipeline <pk.raw> <vk.json>          ProverPipeline: proofs of several witnesses kept in flight, in order (GPU)
+//   frontend_test main_cli <pk.raw> <vk.json> <proof.json>   stub_main_genkeys / stub_main_prove / stub_main_verify on a module class (GPU)
 //   frontend_test verify_cli <vk.json> <proof.json>    stub_main_verify (host only): exit code 0 / 1 / 2 like the reference's
 #include "ethsnarks_hip/stubs.hpp"
 #include "ethsnarks_hip/gadgets.hpp"
@@ -120,6 +121,21 @@ static bool build_merkle29(ProtoboardT &pb) {
     return true;
 }
 
+// a circuit module in the shape stub_genkeys<GadgetT> / stub_main_prove<GadgetT> expect (src/stubs.hpp:23-55): constructed on a
+// protoboard with a name, generate_r1cs_constraints(), generate_r1cs_witness()
+class hash_preimage_module {
+ public:
+    hash_preimage_module(ProtoboardT &pb, const std::string &name)
+        : m_0(make_variable(pb, FieldT(ITEM_A), "m_0")), m_1(make_variable(pb, FieldT(ITEM_B), "m_1")),
+          iv((pb.set_input_sizes(2), make_variable(pb, FieldT("918403109389145570117360101535982733651217667914747213867238065296420114726"), "iv"))),
+          hash(pb, iv, {m_0, m_1}, name + ".hash") {}
+    void generate_r1cs_constraints() { hash.generate_r1cs_constraints(); }
+    void generate_r1cs_witness() { hash.generate_r1cs_witness(); }
+ private:
+    const VariableT m_0, m_1, iv;
+    MiMC_e7_hash_gadget hash;
+};
+
 static bool write_text(const char *path, const std::string &s) { std::ofstream f(path, std::ios::binary); f << s; return (bool)f; }
 
 int main(int argc, char **argv) {
@@ -203,6 +219,18 @@ int main(int argc, char **argv) {
             std::ifstream vf(argv[3], std::ios::binary);
             const std::string vk((std::istreambuf_iterator<char>(vf)), std::istreambuf_iterator<char>());
             ok = ok && got == expect && got.size() == 7 && got[0] != got[1] && stub_verify(vk.c_str(), got[6].c_str());
+            std::cout << (ok ? "VERIFIED" : "REJECTED") << std::endl;
+            return ok ? 0 : 1;
+        }
+        if (mode == "main_cli" && argc == 5) {                // stub_main_genkeys / stub_main_prove / stub_main_verify, the reference's CLI helpers
+            char cmd_g[] = "genkeys", cmd_p[] = "prove";
+            char *g_args[] = {cmd_g, argv[2], argv[3]}, *p_args[] = {cmd_p, argv[2], argv[4]};
+            const char *v_args[] = {"verify", argv[3], argv[4]};
+            bool ok = stub_main_genkeys<hash_preimage_module>("frontend_test", 2, g_args) == 1;      // usage error
+            ok = ok && stub_main_prove<hash_preimage_module>("frontend_test", 2, p_args) == 1;
+            ok = ok && stub_main_genkeys<hash_preimage_module>("frontend_test", 3, g_args) == 0;
+            ok = ok && stub_main_prove<hash_preimage_module>("frontend_test", 3, p_args) == 0;
+            ok = ok && stub_main_verify("frontend_test", 3, v_args) == 0;
             std::cout << (ok ? "VERIFIED" : "REJECTED") << std::endl;
             return ok ? 0 : 1;
         }

@@ -101,6 +101,15 @@ def test_adapter_prover_context_call_sequence(exe, tmp_path):
 
 
 @pytest.mark.gpu
+def test_adapter_cli_helpers(exe, tmp_path):
+    """stub_main_genkeys<GadgetT> -> stub_main_prove<GadgetT> -> stub_main_verify with the reference's argv shapes and exit codes
+    (src/stubs.hpp:36-55, src/stubs.cpp:90-132)"""
+    p = subprocess.run([exe, "main_cli", str(tmp_path / "pk.raw"), str(tmp_path / "vk.json"), str(tmp_path / "proof.json")], capture_output=True, text=True)
+    assert p.returncode == 0 and p.stdout.strip() == "VERIFIED", p.stdout + p.stderr
+    assert "Usage: frontend_test genkeys <pk-output.raw> <vk-output.json>" in p.stderr
+
+
+@pytest.mark.gpu
 def test_adapter_prover_pipeline(exe, tmp_path):
     """ProverPipeline: seven witnesses of the MiMC hash circuit through two contexts (running + staged), proofs in submission
     order and equal to prove()'s, `full()` honoured"""
