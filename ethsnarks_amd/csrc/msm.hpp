@@ -103,15 +103,28 @@ struct MsmShape {
     ChunkRule chunk;
     uint32_t quad = 1;      // lanes per logical thread in the bucket-reduction kernels: 1, or 4 (Curve::*_q) for latency-bound sizes
     uint32_t quad_acc = 1;  // ... and in the accumulation kernel (only while 4 lanes per chunk still fit the machine at once)
-    // largest window with >= 32 entries per bucket on average (n * W entries over 2^(c-1) buckets)
-    static uint32_t pick_c(uint32_t n) {
-        for (uint32_t c = 17; c > 2; c--)      // 17: measured optimum at n = 2^20 (W = 15 windows, 2^16 buckets)
-            if ((uint64_t)n * (254 / c + 1) >= ((uint64_t)MSM_SEG_MIN << (c - 1))) return c;
+    // largest window with >= T entries per bucket on average (n * W entries over 2^(c-1) buckets).  T = 32 for one proof at a time:
+    // the bucket reduction is latency there and a larger window shortens the accumulation chains.  A batch pays the reduction of
+    // every proof's buckets in throughput once its entries fill the machine, and wants fuller buckets: T grows with the entries of
+    // the whole batch, 32 at 2^20.5 of them to 100 from 2^22 on (measured, proofs/s with the window this rule picks against the
+    // single-proof one: MiMC-11 k = 32 8.6k -> 13.3k, k = 64 10.1k -> 16.0k; Merkle-29 k = 8 2.62k -> 2.74k, k = 32 3.58k -> 3.75k;
+    // MiMC-11 k <= 16 and every single proof keep the larger window)
+    static uint32_t pick_c(uint32_t n, uint32_t batch = 1) {
+        for (uint32_t c = 17; c > 2; c--) {    // 17: measured optimum at n = 2^20 (W = 15 windows, 2^16 buckets)
+            const uint64_t entries = (uint64_t)n * (254 / c + 1);
+            uint64_t per_bucket = MSM_SEG_MIN;
+            if (batch > 1) {
+                per_bucket = 32 * entries * batch / 1482910;           // 2^20.5
+                if (per_bucket < MSM_SEG_MIN) per_bucket = MSM_SEG_MIN;
+                if (per_bucket > 100) per_bucket = 100;
+            }
+            if (entries >= (per_bucket << (c - 1))) return c;
+        }
         return 2;
     }
     // batch: proofs per launch sequence the MSM will see (the latency / throughput switches below look at all their entries)
     void set(uint32_t n_, uint32_t c_, uint32_t batch = 1) {
-        n = n_; c = c_ ? c_ : pick_c(n_);
+        n = n_; c = c_ ? c_ : pick_c(n_, batch ? batch : 1);
         if (c < 2) c = 2;
         if (c > 20) c = 20;
         W = 254 / c + 1; nb = 1u << (c - 1);

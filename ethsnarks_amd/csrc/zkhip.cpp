@@ -468,6 +468,8 @@ Range shard_range(uint32_t n, uint32_t rank, uint32_t count) {
 namespace {
 struct DeviceTables {
     uint64_t pk_id = 0; int device = 0; uint32_t rank = 0, count = 1, cbits = 0;
+    uint32_t max_batch = 1;                            // the window choice depends on the batch the contexts are built for (MsmShape::pick_c)
+    uint32_t cA = 0, cB = 0, cH = 0, cL = 0;           // resolved window bits of the four tables
     G1::Affine *tA = nullptr, *tH = nullptr, *tL = nullptr; G2::Affine *tB = nullptr;
     uint32_t *dA_idx = nullptr, *dB_idx = nullptr;
     // the A-, B- and L-query all read the witness: ONE bucket sort of all V+1 witness digits drives every query that
@@ -579,11 +581,11 @@ static int ctx_build(zk_ctx *c, const zk_pk *pk, const zk_csr *A, const zk_csr *
         std::lock_guard<std::mutex> lk(g_tables_mu);
         DeviceTables *t = nullptr;
         for (DeviceTables *e : g_tables)
-            if (e->pk_id == pk->id && e->device == c->device && e->rank == r && e->count == G && e->cbits == c->cfg.multi_exp_c) { t = e; break; }
+            if (e->pk_id == pk->id && e->device == c->device && e->rank == r && e->count == G && e->cbits == c->cfg.multi_exp_c && e->max_batch == c->max_batch) { t = e; break; }
         if (!t) {
             t = new (std::nothrow) DeviceTables();
             if (!t) return ZK_ERR_NOMEM;
-            t->pk_id = pk->id; t->device = c->device; t->rank = r; t->count = G; t->cbits = c->cfg.multi_exp_c;
+            t->pk_id = pk->id; t->device = c->device; t->rank = r; t->count = G; t->cbits = c->cfg.multi_exp_c; t->max_batch = c->max_batch;
             // The A-, B- and L-query all read the witness: ONE bucket sort of the witness digits drives every query that is
             // dense in the window it covers.  Unsharded the window is the whole witness; a shard's window is the span of the
             // witness indices its three base ranges touch (base-range sharding cuts the three queries at about the same place).
@@ -601,7 +603,10 @@ static int ctx_build(zk_ctx *c, const zk_pk *pk, const zk_csr *A, const zk_csr *
             t->share_B = can_share && c->rB.n() >= dense;
             t->share_L = can_share && c->rL.n() >= dense;
             if ((int)t->share_A + (int)t->share_B + (int)t->share_L < 2) t->share_A = t->share_B = t->share_L = false;   // nothing to share
-            t->cW = t->cbits ? t->cbits : MsmShape::pick_c(t->win_n ? t->win_n : 1);
+            auto window = [&](uint32_t n) { return t->cbits ? t->cbits : MsmShape::pick_c(n ? n : 1, t->max_batch); };
+            t->cW = window(t->win_n);
+            t->cA = t->share_A ? t->cW : window(c->rA.n()); t->cB = t->share_B ? t->cW : window(c->rB.n());
+            t->cH = window(c->rH.n()); t->cL = t->share_L ? t->cW : window(c->rL.n());
             int rc = dev_upload(&t->dA_idx, pk->a_idx.data() + c->rA.lo, c->rA.n());
             if (rc == ZK_OK) rc = dev_upload(&t->dB_idx, pk->b_idx.data() + c->rB.lo, c->rB.n());
             // window position -> shard entry: consecutive indices need no map (entry = position - off), else an explicit one
@@ -618,10 +623,10 @@ static int ctx_build(zk_ctx *c, const zk_pk *pk, const zk_csr *A, const zk_csr *
             if (rc == ZK_OK && t->share_A) rc = inverse(pk->a_idx, c->rA, &t->posA, &t->offA);
             if (rc == ZK_OK && t->share_B) rc = inverse(pk->b_idx, c->rB, &t->posB, &t->offB);
             t->offL = c->rL.n() ? nIn + 1 + c->rL.lo - t->win_lo : 0;
-            if (rc == ZK_OK) rc = build_table<G1>(&t->tA, pk->a_val.data() + c->rA.lo, c->rA.n(), t->share_A ? t->cW : t->cbits);
-            if (rc == ZK_OK) rc = build_table<G1>(&t->tH, pk->H.data() + c->rH.lo, c->rH.n(), t->cbits);
-            if (rc == ZK_OK) rc = build_table<G1>(&t->tL, pk->L.data() + c->rL.lo, c->rL.n(), t->share_L ? t->cW : t->cbits);
-            if (rc == ZK_OK) rc = build_table<G2>(&t->tB, pk->b_val.data() + c->rB.lo, c->rB.n(), t->share_B ? t->cW : t->cbits);
+            if (rc == ZK_OK) rc = build_table<G1>(&t->tA, pk->a_val.data() + c->rA.lo, c->rA.n(), t->cA);
+            if (rc == ZK_OK) rc = build_table<G1>(&t->tH, pk->H.data() + c->rH.lo, c->rH.n(), t->cH);
+            if (rc == ZK_OK) rc = build_table<G1>(&t->tL, pk->L.data() + c->rL.lo, c->rL.n(), t->cL);
+            if (rc == ZK_OK) rc = build_table<G2>(&t->tB, pk->b_val.data() + c->rB.lo, c->rB.n(), t->cB);
             if (rc != ZK_OK) {
                 void *dev[] = {t->tA, t->tH, t->tL, t->tB, t->dA_idx, t->dB_idx, t->posA, t->posB};
                 for (void *p : dev) if (p) hipFree(p);
@@ -638,10 +643,10 @@ static int ctx_build(zk_ctx *c, const zk_pk *pk, const zk_csr *A, const zk_csr *
     const bool any_share = t->share_A || t->share_B || t->share_L;
     const uint32_t KB = c->max_batch;
     if (any_share) ZK_TRY(c->mW.alloc(t->win_n, t->cW, nullptr, nullptr, /*sort_only=*/true, KB));
-    ZK_TRY(c->mA.alloc(c->rA.n(), c->cfg.multi_exp_c, t->tA, t->share_A ? &c->mW.sh : nullptr, false, KB));
-    ZK_TRY(c->mH.alloc(c->rH.n(), c->cfg.multi_exp_c, t->tH, nullptr, false, KB));
-    ZK_TRY(c->mL.alloc(c->rL.n(), c->cfg.multi_exp_c, t->tL, t->share_L ? &c->mW.sh : nullptr, false, KB));
-    ZK_TRY(c->mB.alloc(c->rB.n(), c->cfg.multi_exp_c, t->tB, t->share_B ? &c->mW.sh : nullptr, false, KB));
+    ZK_TRY(c->mA.alloc(c->rA.n(), t->cA, t->tA, t->share_A ? &c->mW.sh : nullptr, false, KB));
+    ZK_TRY(c->mH.alloc(c->rH.n(), t->cH, t->tH, nullptr, false, KB));
+    ZK_TRY(c->mL.alloc(c->rL.n(), t->cL, t->tL, t->share_L ? &c->mW.sh : nullptr, false, KB));
+    ZK_TRY(c->mB.alloc(c->rB.n(), t->cB, t->tB, t->share_B ? &c->mW.sh : nullptr, false, KB));
     ZK_TRY(c->cA.upload(A, V, KB)); ZK_TRY(c->cB.upload(B, V, KB)); ZK_TRY(c->cC.upload(C, V, KB));
     ZK_HIP(hipMalloc(&c->d_w, 32 * (size_t)(V + 1) * KB));
     // A | B | C polynomials of all proofs of a batch: [A: KB x m][B: KB x m][C: KB x m], one batched NTT launch per pass
