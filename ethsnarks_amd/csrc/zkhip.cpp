@@ -536,6 +536,10 @@ struct zk_ctx {
     NttTables tab;
     MsmWork<G1> mA, mH, mL, mW; MsmWork<G2> mB;       // mW: sort-only, the shared witness-digit sort
     hipStream_t s_main = nullptr, s_acc = nullptr, s_a = nullptr, s_b = nullptr, s_l = nullptr;
+    hipStream_t s_h = nullptr;                 // the H pipeline (row evaluations, transforms, H sort and tail) beside the witness sorts; == s_main when not split
+    hipEvent_t ev_up = nullptr, ev_sort_h = nullptr;
+    bool h_stream_made = false;
+    bool latency_call = false;                 // the proof being queued came through a synchronous entry point (zk_prove ...)
     hipEvent_t ev_sort = nullptr;              // a finished bucket sort on s_main releases its accumulation on s_acc
     hipEvent_t ev_start = nullptr, ev_w = nullptr, ev_h = nullptr, ev_a0 = nullptr, ev_a1 = nullptr, ev_b0 = nullptr, ev_b1 = nullptr,
                ev_l0 = nullptr, ev_l1 = nullptr, ev_h1 = nullptr, ev_h0 = nullptr;
@@ -556,7 +560,10 @@ struct zk_ctx {
         if (serial) s_a = s_b = s_l = nullptr;
         if (s_acc == s_main) s_acc = nullptr;
         if (ev_sort) hipEventDestroy(ev_sort);
-        hipStream_t ss[] = {s_main, s_acc, s_a, s_b, s_l};
+        s_h = nullptr;                                   // never owned: s_main or s_l
+        if (ev_up) hipEventDestroy(ev_up);
+        if (ev_sort_h) hipEventDestroy(ev_sort_h);
+        hipStream_t ss[] = {s_main, s_acc, s_a, s_b, s_l, s_h};
         for (auto s : ss) if (s) hipStreamDestroy(s);
         hipEvent_t ee[] = {ev_start, ev_w, ev_h, ev_a0, ev_a1, ev_b0, ev_b1, ev_l0, ev_l1, ev_h1, ev_h0};
         for (auto e : ee) if (e) hipEventDestroy(e);
@@ -681,6 +688,7 @@ static int ctx_build(zk_ctx *c, const zk_pk *pk, const zk_csr *A, const zk_csr *
     if (c->serial || (split && split[0] == '0')) c->s_acc = c->s_main;
     else ZK_HIP(hipStreamCreateWithPriority(&c->s_acc, hipStreamNonBlocking, prio(pr[1])));
     ZK_HIP(hipEventCreate(&c->ev_sort));
+    c->s_h = c->s_main;                                               // small proofs move the H pipeline to a tail stream (prove_enqueue)
     if (c->serial) { c->s_a = c->s_b = c->s_l = c->s_main; }
     else {
         ZK_HIP(hipStreamCreateWithPriority(&c->s_a, hipStreamNonBlocking, prio(pr[2])));
@@ -723,8 +731,7 @@ extern "C" void zk_ctx_destroy(zk_ctx *ctx) { delete ctx; }
 
 // ---- "Compute the polynomial H" (tcc:460-475) on s_main; result in d_t (natural order), h[m-1] copied to h_tail
 // for the k = cur_batch proofs in flight: polynomials laid out [A: k x m][B: k x m][C: k x m] in d_a, h of proof p at d_t + p m
-static int enqueue_compute_h(zk_ctx *c) {
-    hipStream_t st = c->s_main;
+static int enqueue_compute_h(zk_ctx *c, hipStream_t st) {
     const uint32_t m = c->m, k = c->cur_batch, ws = c->V + 1;
     fe *a = c->d_a, *b = c->d_a + (size_t)m * k, *cc = c->d_a + 2 * (size_t)m * k;
     // rows [nC, m) of every polynomial are padding (the input-consistency rows of A are set below): only they need zeroing,
@@ -798,7 +805,7 @@ static int prove_submit_impl(zk_ctx *c, const uint64_t *witness, int canonical, 
     c->cur_batch = k;
     const int rc = prove_enqueue(c, witness, canonical, resident, d_h);
     if (rc != ZK_OK) {      // part of the proof may be queued: drain it so that the next submit cannot overwrite buffers still in use
-        hipStreamSynchronize(c->s_main); hipStreamSynchronize(c->s_acc); hipStreamSynchronize(c->s_a); hipStreamSynchronize(c->s_b); hipStreamSynchronize(c->s_l);
+        hipStreamSynchronize(c->s_main); hipStreamSynchronize(c->s_acc); hipStreamSynchronize(c->s_a); hipStreamSynchronize(c->s_b); hipStreamSynchronize(c->s_l); hipStreamSynchronize(c->s_h);
         return rc;
     }
     c->in_flight = true;
@@ -813,11 +820,48 @@ static int prove_enqueue(zk_ctx *c, const uint64_t *witness, int canonical, int 
     const DeviceTables *t = c->tables;
     const uint32_t k = c->cur_batch, ws = c->V + 1;             // proofs of this launch sequence; witness stride
     auto release = [&]() -> int { if (q != m) { ZK_HIP(hipEventRecord(c->ev_sort, m)); ZK_HIP(hipStreamWaitEvent(q, c->ev_sort, 0)); } return ZK_OK; };
+    // the H pipeline: on s_main behind the witness sorts, or -- split -- on its own stream beside them (it only needs the upload);
+    // its launches are queued right after the first sort, ahead of the reductions' (the host enqueues ~5 us per launch)
+    // Small proofs (domains up to 2^15, unbatched: fewer than 3 * 2^18 bucket entries per query) run the H pipeline beside the witness
+    // sorts instead of behind them; it borrows a tail stream -- a sixth stream per context, even an idle one, changes how the
+    // runtime maps streams to its hardware queues (created with the others it cost the pipelined 2^20 schedule 7 %, created on first
+    // use it slowed the very proofs it was meant for by 15 %).  Which one is measured (tools/dev_sync_latency.py, bench.py):
+    //  * a synchronous call (zk_prove, zk_prove_partial: the caller waits for this one proof) borrows the A-tail stream: the A tail
+    //    is early and not critical, and at the end the L tail and the H tail run side by side -- Merkle-29 1.55 -> 1.23 ms, MiMC-11
+    //    1.21 -> 1.10 ms, 2^14 1.46 -> 1.35 ms (the B-tail stream, the longest tail's, makes everything 30-50 % slower; 2^16: no gain);
+    //  * queued proofs (zk_prove_submit, several contexts in flight) borrow the L-tail stream: Merkle-29 849 -> 949, MiMC-11
+    //    1 083 -> 1 303 proofs/s with three contexts (the A-tail stream: no gain there; 2^16 and larger, and batches: -2 ... -7 %).
+    const uint64_t entries = (uint64_t)c->mH.sh.max_entries() * k;
+    const char *hs_env = getenv("ZK_H_STREAM");                       // tuning aids: ZK_H_STREAM=0 / 1 forces it, ZK_H_BORROW=a / l / b picks the stream
+    const bool want_split = !c->serial && (hs_env ? hs_env[0] == '1' : entries < (3ull << 18));
+    if (want_split && !c->h_stream_made) {
+        ZK_HIP(hipEventCreateWithFlags(&c->ev_up, hipEventDisableTiming));
+        ZK_HIP(hipEventCreateWithFlags(&c->ev_sort_h, hipEventDisableTiming));
+        c->h_stream_made = true;
+    }
+    if (want_split) {
+        const char *bw = getenv("ZK_H_BORROW");
+        const char which = bw ? bw[0] : (c->latency_call ? 'a' : 'l');
+        c->s_h = which == 'a' ? c->s_a : which == 'b' ? c->s_b : c->s_l;
+    }
+    const bool split_h = want_split && c->h_stream_made;
+    hipStream_t hs = split_h ? c->s_h : m;
+    auto h_pipeline = [&]() -> int {
+        ZK_HIP(hipEventRecord(c->ev_h0, hs));
+        if (!d_h) ZK_TRY(enqueue_compute_h(c, hs));
+        else memset(c->h_tail, 0, 32);                          // the rank that computed h has checked its degree
+        ZK_HIP(hipEventRecord(c->ev_h, hs));
+        ZK_TRY(c->mH.enqueue_sort(d_h ? d_h : c->d_t + c->rH.lo, nullptr, c->rH.n(), 0, hs, k, c->m));   // tcc:510-518
+        if (split_h) ZK_HIP(hipEventRecord(c->ev_sort_h, hs));
+        return ZK_OK;
+    };
+    if (split_h) { ZK_HIP(hipEventRecord(c->ev_up, m)); ZK_HIP(hipStreamWaitEvent(hs, c->ev_up, 0)); }
     if (t->share_A || t->share_B || t->share_L) {               // one sort of the witness digits of the window
         ZK_TRY(c->mW.enqueue_sort(c->d_w + t->win_lo, nullptr, t->win_n, 0, m, k, ws));
         ZK_TRY(release());
     }
     if (!t->share_B) { ZK_TRY(c->mB.enqueue_sort(c->d_w, c->dB_idx, c->rB.n(), 0, m, k, ws)); ZK_TRY(release()); }
+    if (split_h) ZK_TRY(h_pipeline());
     ZK_HIP(hipEventRecord(c->ev_b0, q));
     ZK_TRY(c->mB.enqueue_reduce(t->share_B ? c->mW.view_for(t->offB, t->posB) : c->mB.view(), q, c->s_b));    // tcc:499-506
     ZK_HIP(hipEventRecord(c->ev_b1, c->s_b));
@@ -829,14 +873,10 @@ static int prove_enqueue(zk_ctx *c, const uint64_t *witness, int canonical, int 
     ZK_HIP(hipEventRecord(c->ev_l0, q));
     ZK_TRY(c->mL.enqueue_reduce(t->share_L ? c->mW.view_for(t->offL) : c->mL.view(), q, c->s_l));            // tcc:522-530
     ZK_HIP(hipEventRecord(c->ev_l1, c->s_l));
-    ZK_HIP(hipEventRecord(c->ev_h0, m));
-    if (!d_h) ZK_TRY(enqueue_compute_h(c));
-    else memset(c->h_tail, 0, 32);                              // the rank that computed h has checked its degree
-    ZK_HIP(hipEventRecord(c->ev_h, m));
-    ZK_TRY(c->mH.enqueue_sort(d_h ? d_h : c->d_t + c->rH.lo, nullptr, c->rH.n(), 0, m, k, c->m));   // tcc:510-518
-    ZK_TRY(release());
-    ZK_TRY(c->mH.enqueue_reduce(c->mH.view(), q, m));
-    ZK_HIP(hipEventRecord(c->ev_h1, m));
+    if (!split_h) { ZK_TRY(h_pipeline()); ZK_TRY(release()); }
+    else ZK_HIP(hipStreamWaitEvent(q, c->ev_sort_h, 0));
+    ZK_TRY(c->mH.enqueue_reduce(c->mH.view(), q, hs));
+    ZK_HIP(hipEventRecord(c->ev_h1, hs));
     return ZK_OK;
 }
 
@@ -846,7 +886,7 @@ static int prove_collect_impl(zk_ctx *c, zk_partials *out, zk_timings *tm) {    
     ZK_TRY(use_device(c->device));
     c->in_flight = false;
     ZK_HIP(hipStreamSynchronize(c->s_acc)); ZK_HIP(hipStreamSynchronize(c->s_a)); ZK_HIP(hipStreamSynchronize(c->s_b));
-    ZK_HIP(hipStreamSynchronize(c->s_l)); ZK_HIP(hipStreamSynchronize(c->s_main));
+    ZK_HIP(hipStreamSynchronize(c->s_l)); ZK_HIP(hipStreamSynchronize(c->s_h)); ZK_HIP(hipStreamSynchronize(c->s_main));
     for (uint32_t p = 0; p < c->cur_batch; p++)
         if (!Fr::is_zero(c->h_tail[p])) return fail(ZK_ERR_DEGREE, "h[m-1] != 0: the witness does not satisfy the constraint system");
     double t0 = now_ms();
@@ -877,7 +917,10 @@ static int prove_collect_impl(zk_ctx *c, zk_partials *out, zk_timings *tm) {    
 
 static int prove_partial_impl(zk_ctx *c, const uint64_t *witness, int canonical, zk_partials *out, zk_timings *tm) {
     if (!out) return fail(ZK_ERR_ARG, "null argument");
-    ZK_TRY(prove_submit_impl(c, witness, canonical));
+    if (c) c->latency_call = true;                              // synchronous: one proof, the caller waits for it
+    const int rc_submit = prove_submit_impl(c, witness, canonical);
+    if (c) c->latency_call = false;
+    ZK_TRY(rc_submit);
     return prove_collect_impl(c, out, tm);
 }
 // asynchronous form: enqueue a proof and return; collect later (lets two contexts keep the GPU full)
@@ -1386,7 +1429,7 @@ extern "C" int zk_witness_map(zk_ctx *c, const uint64_t *witness, int canonical,
     ZK_TRY(use_device(c->device));
     c->cur_batch = 1;
     ZK_TRY(upload_witness(c, witness, canonical));
-    ZK_TRY(enqueue_compute_h(c));
+    ZK_TRY(enqueue_compute_h(c, c->s_main));
     ZK_HIP(hipStreamSynchronize(c->s_main));
     ZK_HIP(hipMemcpy(h_out, c->d_t, 32 * (size_t)c->m, hipMemcpyDeviceToHost));
     memset(h_out + 4 * (size_t)c->m, 0, 32);
