@@ -201,9 +201,10 @@ struct MsmWork {
     int enqueue(const fe *scalars, const uint32_t *gather, uint32_t n, int canonical, hipStream_t st, hipStream_t st_tail, uint32_t batch = 1, uint32_t stride = 0);
     // the two halves: the bucket sort of this MSM's scalars, and accumulation + reduction driven by a sort view
     int enqueue_sort(const fe *scalars, const uint32_t *gather, uint32_t n, int canonical, hipStream_t st, uint32_t batch = 1, uint32_t stride = 0);
-    int enqueue_reduce(const SortView &v, hipStream_t st, hipStream_t st_tail);
+    // tail_lanes: lanes per logical thread of the bucket-reduction kernels for this call (0 = the shape's choice, sh.quad)
+    int enqueue_reduce(const SortView &v, hipStream_t st, hipStream_t st_tail, uint32_t tail_lanes = 0);
     template <int Q> int launch_reduce(uint32_t K, uint32_t groups, hipStream_t st);
-    uint32_t tree_levels(uint32_t groups) const;
+    uint32_t tree_levels(uint32_t groups, uint32_t lanes) const;
     const uint32_t *cur_off = nullptr;          // bucket offsets of the sort driving the current reduction
     uint32_t sort_batch = 1;                    // batch of the last enqueue_sort
     SortView view() const { SortView v; v.sorted = sorted; v.off = off; v.batch = sort_batch; v.nb = sh.nb * sort_batch; v.entries_bound = (uint32_t)((uint64_t)table_n * sh.W * sort_batch); return v; }

@@ -353,7 +353,7 @@ int MsmWork<C>::alloc(uint32_t n, uint32_t c, typename C::Affine *shared_table, 
     ZK_HIP(hipMalloc(&pieces, sizeof(typename C::XYZZ) * n_pieces));
     ZK_HIP(hipMalloc(&bucket, sizeof(typename C::XYZZ) * sh.nb * B));
     ZK_HIP(hipMalloc(&partial_a, sizeof(typename C::XYZZ) * ((size_t)groups * B + 1)));
-    ZK_HIP(hipMalloc(&partial_b, sizeof(typename C::XYZZ) * ((size_t)zk_div_up(groups, MSM_TREE / sh.quad) * B + 1)));
+    ZK_HIP(hipMalloc(&partial_b, sizeof(typename C::XYZZ) * ((size_t)zk_div_up(groups, MSM_TREE / 4) * B + 1)));   // sized for 4 lanes per thread (the smaller fan-in), whichever a call uses
     ZK_HIP(hipHostMalloc(&host_result, sizeof(typename C::XYZZ) * B, hipHostMallocDefault));
     ZK_HIP(hipEventCreate(&ev_acc0)); ZK_HIP(hipEventCreate(&ev_acc1));
     return ZK_OK;
@@ -398,9 +398,9 @@ int MsmWork<C>::enqueue_sort(const fe *scalars, const uint32_t *gather, uint32_t
 
 // number of tree-sum launches that take `groups` partials to one point (ping-pong partial_a -> partial_b -> ...)
 template <class C>
-uint32_t MsmWork<C>::tree_levels(uint32_t groups) const {
+uint32_t MsmWork<C>::tree_levels(uint32_t groups, uint32_t lanes) const {
     uint32_t levels = 0, count = groups;
-    do { count = zk_div_up(count, MSM_TREE / sh.quad); levels++; } while (count > 1);
+    do { count = zk_div_up(count, MSM_TREE / lanes); levels++; } while (count > 1);
     return levels;
 }
 
@@ -425,7 +425,7 @@ int MsmWork<C>::launch_reduce(uint32_t K, uint32_t groups, hipStream_t st) {    
 }
 
 template <class C>
-int MsmWork<C>::enqueue_reduce(const SortView &v, hipStream_t st, hipStream_t st_tail) {
+int MsmWork<C>::enqueue_reduce(const SortView &v, hipStream_t st, hipStream_t st_tail, uint32_t tail_lanes) {
     if (!v.sorted || !v.batch || v.batch > max_batch || v.nb != sh.nb * v.batch) return fail_msg(ZK_ERR_ARG, "MSM reduce: the driving sort has a different bucket count");   // a borrowed sort must have this MSM's buckets
     cur_batch = v.batch;
     const uint32_t nb = v.nb;                                   // buckets of all proofs of the batch
@@ -444,9 +444,10 @@ int MsmWork<C>::enqueue_reduce(const SortView &v, hipStream_t st, hipStream_t st
     ZK_HIP(hipEventRecord(ev_acc1, st));
     if (st_tail != st) { ZK_HIP(hipStreamWaitEvent(st_tail, ev_acc1, 0)); st = st_tail; }
     cur_off = v.off;
-    const int rc = sh.quad == 4 ? launch_reduce<4>(K, groups, st) : launch_reduce<1>(K, groups, st);
+    const uint32_t lanes = tail_lanes == 4 || tail_lanes == 1 ? tail_lanes : sh.quad;
+    const int rc = lanes == 4 ? launch_reduce<4>(K, groups, st) : launch_reduce<1>(K, groups, st);
     if (rc != ZK_OK) return rc;
-    typename C::XYZZ *cur = (tree_levels(groups) & 1) ? partial_b : partial_a;
+    typename C::XYZZ *cur = (tree_levels(groups, lanes) & 1) ? partial_b : partial_a;
     ZK_HIP(hipGetLastError());
     ZK_HIP(hipMemcpyAsync(host_result, cur, sizeof(typename C::XYZZ) * cur_batch, hipMemcpyDeviceToHost, st));
     if (dev_result) {
