@@ -783,10 +783,14 @@ static int enqueue_h_from_chains(zk_ctx *c, const fe *a, const fe *b, const fe *
 // resident: 0 = host buffer, 1 = device buffer of the caller, 2 = staged earlier (zk_prove_stage): already in d_w
 static int upload_witness(zk_ctx *c, const uint64_t *witness, int canonical, int resident = 0) {
     const size_t n = (size_t)(c->V + 1) * c->cur_batch;          // the witnesses of a batch are contiguous
-    if (!resident) memcpy(c->h_w, witness, 32 * n);
+    // a queued proof copies the caller's buffer into pinned memory (the caller may reuse it at once, the H2D copy is asynchronous);
+    // a synchronous call hands the caller's buffer to the runtime, which pipelines its own staging with the DMA
+    const bool direct = !resident && c->latency_call && getenv("ZK_NO_DIRECT_H2D") == nullptr;
+    if (!resident && !direct) memcpy(c->h_w, witness, 32 * n);
     if (resident == 2) ZK_HIP(hipStreamWaitEvent(c->s_main, c->ev_staged, 0));
     ZK_HIP(hipEventRecord(c->ev_start, c->s_main));
     if (resident == 1) ZK_HIP(hipMemcpyAsync(c->d_w, witness, 32 * n, hipMemcpyDeviceToDevice, c->s_main));
+    else if (direct) ZK_HIP(hipMemcpyAsync(c->d_w, witness, 32 * n, hipMemcpyHostToDevice, c->s_main));
     else if (!resident) ZK_HIP(hipMemcpyAsync(c->d_w, c->h_w, 32 * n, hipMemcpyHostToDevice, c->s_main));
     if (canonical) ZK_LAUNCH(k_to_mont, zk_div_up(n, 256), 256, c->s_main, c->d_w, (uint32_t)n);
     ZK_HIP(hipEventRecord(c->ev_w, c->s_main));
