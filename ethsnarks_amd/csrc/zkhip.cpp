@@ -106,11 +106,12 @@ static_assert(sizeof(zk_partials) == 640, "zk_partials layout");
 // ================================================================ library / device
 extern "C" const char *zk_version(void) {
 #ifdef ZK_EMUL
-    return "zkhip 0.1.0 (CPU EMULATION BUILD - tests only)";
+    return "zkhip 0.3.0 (CPU EMULATION BUILD - tests only)";
 #else
-    return "zkhip 0.1.0 (gfx950)";
+    return "zkhip 0.3.0 (gfx950)";
 #endif
 }
+extern "C" uint32_t zk_abi_version(void) { return ZK_ABI_VERSION; }
 extern "C" const char *zk_strerror(int code) {
     switch (code) {
     case ZK_OK: return "ok";
@@ -511,8 +512,39 @@ void tables_release(DeviceTables *t) {
 }
 }  // namespace
 
+// ---- streams outlive the contexts that use them.  The runtime maps every stream to one of a few hardware queues when the
+// stream is created and tears the queue down with its last stream; a context set created after an earlier one was destroyed
+// got another mapping and proved 6 % slower at 2^20 (9.4 -> 10.0 ms per proof, same kernels: tools/dev_second_leg.py).  A closed
+// context therefore parks its streams here, by device, role and priority, and the next context of that role takes them in the
+// order they were parked: the n-th context of a process always runs on the same queues.  Parked streams are idle (the
+// destructor drains them) and are released with the process.
+namespace {
+struct ParkedStream { int device, role, prio; hipStream_t st; };
+std::mutex g_streams_mu;
+std::vector<ParkedStream> g_streams;
+int stream_take(hipStream_t *out, int device, int role, int prio) {
+    {
+        std::lock_guard<std::mutex> lk(g_streams_mu);
+        for (size_t i = 0; i < g_streams.size(); i++)
+            if (g_streams[i].device == device && g_streams[i].role == role && g_streams[i].prio == prio) {
+                *out = g_streams[i].st; g_streams.erase(g_streams.begin() + i); return ZK_OK;
+            }
+    }
+    ZK_HIP(hipStreamCreateWithPriority(out, hipStreamNonBlocking, prio));
+    return ZK_OK;
+}
+void stream_park(hipStream_t st, int device, int role, int prio) {
+    if (!st) return;
+    (void)hipStreamSynchronize(st);
+    std::lock_guard<std::mutex> lk(g_streams_mu);
+    g_streams.push_back(ParkedStream{device, role, prio, st});
+}
+enum { ROLE_MAIN = 0, ROLE_ACC, ROLE_A, ROLE_B, ROLE_L, ROLE_COPY };
+}  // namespace
+
 struct zk_ctx {
     int device = 0;
+    int stream_prio[6] = {0, 0, 0, 0, 0, 0};   // priority each role's stream was taken with (stream_park files it under the same key)
     DeviceTables *tables = nullptr;
     bool serial = false;
     bool in_flight = false;
@@ -540,6 +572,10 @@ struct zk_ctx {
     hipEvent_t ev_up = nullptr, ev_sort_h = nullptr;
     bool h_stream_made = false;
     bool latency_call = false;                 // the proof being queued came through a synchronous entry point (zk_prove ...)
+    // tuning aids, read from the environment ONCE at context creation (never on the proving path)
+    bool env_no_direct_h2d = false;            // ZK_NO_DIRECT_H2D: synchronous proofs stage the witness through pinned memory too
+    int env_h_stream = -1;                     // ZK_H_STREAM=0 / 1 forces the H pipeline onto s_main / a borrowed tail stream (-1: by size)
+    char env_h_borrow = 0;                     // ZK_H_BORROW=a / l / b picks the borrowed stream (0: by entry point)
     hipEvent_t ev_sort = nullptr;              // a finished bucket sort on s_main releases its accumulation on s_acc
     hipEvent_t ev_start = nullptr, ev_w = nullptr, ev_h = nullptr, ev_a0 = nullptr, ev_a1 = nullptr, ev_b0 = nullptr, ev_b1 = nullptr,
                ev_l0 = nullptr, ev_l1 = nullptr, ev_h1 = nullptr, ev_h0 = nullptr;
@@ -550,7 +586,7 @@ struct zk_ctx {
         if (h_w) hipHostFree(h_w);
         if (d_w2) hipFree(d_w2);
         if (h_w2) hipHostFree(h_w2);
-        if (s_copy) hipStreamDestroy(s_copy);
+        stream_park(s_copy, device, ROLE_COPY, stream_prio[ROLE_COPY]);
         if (ev_staged) hipEventDestroy(ev_staged);
         if (h_tail) hipHostFree(h_tail);
         cA.release(); cB.release(); cC.release();
@@ -563,8 +599,8 @@ struct zk_ctx {
         s_h = nullptr;                                   // never owned: s_main or s_l
         if (ev_up) hipEventDestroy(ev_up);
         if (ev_sort_h) hipEventDestroy(ev_sort_h);
-        hipStream_t ss[] = {s_main, s_acc, s_a, s_b, s_l, s_h};
-        for (auto s : ss) if (s) hipStreamDestroy(s);
+        stream_park(s_main, device, ROLE_MAIN, stream_prio[ROLE_MAIN]); stream_park(s_acc, device, ROLE_ACC, stream_prio[ROLE_ACC]);
+        stream_park(s_a, device, ROLE_A, stream_prio[ROLE_A]); stream_park(s_b, device, ROLE_B, stream_prio[ROLE_B]); stream_park(s_l, device, ROLE_L, stream_prio[ROLE_L]);
         hipEvent_t ee[] = {ev_start, ev_w, ev_h, ev_a0, ev_a1, ev_b0, ev_b1, ev_l0, ev_l1, ev_h1, ev_h0};
         for (auto e : ee) if (e) hipEventDestroy(e);
     }
@@ -681,19 +717,23 @@ static int ctx_build(zk_ctx *c, const zk_pk *pk, const zk_csr *A, const zk_csr *
     const char *pr = getenv("ZK_PRIOS");                              // tuning aid
     if (!pr || strlen(pr) != 5) pr = "hllhl";
     auto prio = [&](char ch) { return ch == 'h' ? prio_hi : ch == 'l' ? prio_lo : (prio_hi + prio_lo) / 2; };
-    ZK_HIP(hipStreamCreateWithPriority(&c->s_main, hipStreamNonBlocking, prio(pr[0])));
+    for (int i = 0; i < 5; i++) c->stream_prio[i] = prio(pr[i]);
+    ZK_TRY(stream_take(&c->s_main, c->device, ROLE_MAIN, c->stream_prio[ROLE_MAIN]));
+    c->env_no_direct_h2d = getenv("ZK_NO_DIRECT_H2D") != nullptr;
+    if (const char *e = getenv("ZK_H_STREAM")) c->env_h_stream = e[0] == '1' ? 1 : 0;
+    if (const char *e = getenv("ZK_H_BORROW")) c->env_h_borrow = e[0];
     const char *serial = getenv("ZK_SERIAL");
     c->serial = (serial && serial[0] == '1') || c->cfg.schedule == ZK_SCHED_ONE_STREAM;
     const char *split = getenv("ZK_SPLIT_STREAMS");
     if (c->serial || (split && split[0] == '0')) c->s_acc = c->s_main;
-    else ZK_HIP(hipStreamCreateWithPriority(&c->s_acc, hipStreamNonBlocking, prio(pr[1])));
+    else ZK_TRY(stream_take(&c->s_acc, c->device, ROLE_ACC, c->stream_prio[ROLE_ACC]));
     ZK_HIP(hipEventCreate(&c->ev_sort));
     c->s_h = c->s_main;                                               // small proofs move the H pipeline to a tail stream (prove_enqueue)
     if (c->serial) { c->s_a = c->s_b = c->s_l = c->s_main; }
     else {
-        ZK_HIP(hipStreamCreateWithPriority(&c->s_a, hipStreamNonBlocking, prio(pr[2])));
-        ZK_HIP(hipStreamCreateWithPriority(&c->s_b, hipStreamNonBlocking, prio(pr[3])));
-        ZK_HIP(hipStreamCreateWithPriority(&c->s_l, hipStreamNonBlocking, prio(pr[4])));
+        ZK_TRY(stream_take(&c->s_a, c->device, ROLE_A, c->stream_prio[ROLE_A]));
+        ZK_TRY(stream_take(&c->s_b, c->device, ROLE_B, c->stream_prio[ROLE_B]));
+        ZK_TRY(stream_take(&c->s_l, c->device, ROLE_L, c->stream_prio[ROLE_L]));
     }
     hipEvent_t *ee[] = {&c->ev_start, &c->ev_w, &c->ev_h, &c->ev_a0, &c->ev_a1, &c->ev_b0, &c->ev_b1, &c->ev_l0, &c->ev_l1, &c->ev_h1, &c->ev_h0};
     for (auto e : ee) ZK_HIP(hipEventCreate(e));
@@ -726,6 +766,13 @@ extern "C" int zk_ctx_create(const zk_pk *pk, const zk_csr *A, const zk_csr *B, 
     if (rc != ZK_OK) { delete c; return rc; }
     *out = c;
     return ZK_OK;
+}
+// clients built against another layout of zk_config pass the size THEY know: missing trailing members read as 0 (their defaults)
+extern "C" int zk_ctx_create_sized(const zk_pk *pk, const zk_csr *A, const zk_csr *B, const zk_csr *C,
+                                   uint32_t nC, uint32_t nIn, uint32_t V, const zk_config *cfg, size_t cfg_size, zk_ctx **out) {
+    zk_config full{};
+    if (cfg) memcpy(&full, cfg, cfg_size < sizeof(full) ? cfg_size : sizeof(full));
+    return zk_ctx_create(pk, A, B, C, nC, nIn, V, cfg ? &full : nullptr, out);
 }
 extern "C" void zk_ctx_destroy(zk_ctx *ctx) { delete ctx; }
 
@@ -785,7 +832,7 @@ static int upload_witness(zk_ctx *c, const uint64_t *witness, int canonical, int
     const size_t n = (size_t)(c->V + 1) * c->cur_batch;          // the witnesses of a batch are contiguous
     // a queued proof copies the caller's buffer into pinned memory (the caller may reuse it at once, the H2D copy is asynchronous);
     // a synchronous call hands the caller's buffer to the runtime, which pipelines its own staging with the DMA
-    const bool direct = !resident && c->latency_call && getenv("ZK_NO_DIRECT_H2D") == nullptr;
+    const bool direct = !resident && c->latency_call && !c->env_no_direct_h2d;
     if (!resident && !direct) memcpy(c->h_w, witness, 32 * n);
     if (resident == 2) ZK_HIP(hipStreamWaitEvent(c->s_main, c->ev_staged, 0));
     ZK_HIP(hipEventRecord(c->ev_start, c->s_main));
@@ -840,16 +887,15 @@ static int prove_enqueue(zk_ctx *c, const uint64_t *witness, int canonical, int 
     //  * queued proofs (zk_prove_submit, several contexts in flight) borrow the L-tail stream: Merkle-29 849 -> 949, MiMC-11
     //    1 083 -> 1 303 proofs/s with three contexts (the A-tail stream: no gain there; 2^16 and larger, and batches: -2 ... -7 %).
     const uint64_t entries = (uint64_t)c->mH.sh.max_entries() * k;
-    const char *hs_env = getenv("ZK_H_STREAM");                       // tuning aids: ZK_H_STREAM=0 / 1 forces it, ZK_H_BORROW=a / l / b picks the stream
-    const bool want_split = !c->serial && (hs_env ? hs_env[0] == '1' : entries < (3ull << 18));
+    // tuning aids (cached at context creation): ZK_H_STREAM=0 / 1 forces it, ZK_H_BORROW=a / l / b picks the stream
+    const bool want_split = !c->serial && (c->env_h_stream >= 0 ? c->env_h_stream == 1 : entries < (3ull << 18));
     if (want_split && !c->h_stream_made) {
         ZK_HIP(hipEventCreateWithFlags(&c->ev_up, hipEventDisableTiming));
         ZK_HIP(hipEventCreateWithFlags(&c->ev_sort_h, hipEventDisableTiming));
         c->h_stream_made = true;
     }
     if (want_split) {
-        const char *bw = getenv("ZK_H_BORROW");
-        const char which = bw ? bw[0] : (c->latency_call ? 'a' : 'l');
+        const char which = c->env_h_borrow ? c->env_h_borrow : (c->latency_call ? 'a' : 'l');
         c->s_h = which == 'a' ? c->s_a : which == 'b' ? c->s_b : c->s_l;
     }
     const bool split_h = want_split && c->h_stream_made;
@@ -945,7 +991,10 @@ extern "C" int zk_prove_stage(zk_ctx *c, const uint64_t *witnesses, uint32_t k, 
     if (!c->d_w2) {
         ZK_HIP(hipMalloc(&c->d_w2, cap));
         ZK_HIP(hipHostMalloc(&c->h_w2, cap, hipHostMallocDefault));
-        ZK_HIP(hipStreamCreateWithFlags(&c->s_copy, hipStreamNonBlocking));
+        int lo = 0, hi = 0;
+        ZK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        c->stream_prio[ROLE_COPY] = (lo + hi) / 2;
+        ZK_TRY(stream_take(&c->s_copy, c->device, ROLE_COPY, c->stream_prio[ROLE_COPY]));
         ZK_HIP(hipEventCreateWithFlags(&c->ev_staged, hipEventDisableTiming));
     }
     ZK_HIP(hipStreamSynchronize(c->s_copy));                    // (the previous staged copy out of h_w2 has long finished; cheap)
@@ -961,8 +1010,10 @@ extern "C" int zk_prove_submit_staged(zk_ctx *c) {
     if (c->in_flight) return fail(ZK_ERR_ARG, "a proof is already in flight on this context (collect it first)");
     std::swap(c->d_w, c->d_w2);                                 // the collected proof no longer reads the old buffer
     const uint32_t k = c->staged_k;
+    const int rc = prove_submit_impl(c, (const uint64_t *)c->d_w, c->staged_canonical, 2, k);
+    if (rc != ZK_OK) { std::swap(c->d_w, c->d_w2); return rc; }    // nothing is in flight (the failed submit was drained): the staged witness stays staged and can be submitted again
     c->staged_k = 0;
-    return prove_submit_impl(c, (const uint64_t *)c->d_w, c->staged_canonical, 2, k);
+    return ZK_OK;
 }
 // ---- SURVEY 8(e) option 2: the transform chains of the witness map on different ranks (ethsnarks_amd/sharded.py drives it)
 extern "C" int zk_chain_submit(zk_ctx *c, const uint64_t *witness, int canonical, int which) {

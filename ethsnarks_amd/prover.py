@@ -54,11 +54,13 @@ class ZkTimings(C.Structure):
         return {n: float(getattr(self, n)) for n, _ in self._fields_}
 
 
+ABI_VERSION = 3          # include/zkhip.h ZK_ABI_VERSION
+
 EXPORTS = [
-    "zk_version", "zk_strerror", "zk_last_error", "zk_device_count",
+    "zk_version", "zk_abi_version", "zk_strerror", "zk_last_error", "zk_device_count",
     "zk_pk_load_raw", "zk_pk_save_raw", "zk_pk_from_bellman_json", "zk_pk_bellman2ethsnarks", "zk_pk_alt2mcl", "zk_pk_mcl2nozk", "zk_pk_from_parts", "zk_pk_sizes", "zk_pk_part", "zk_pk_free",
     "zk_keygen", "zk_vk_to_json", "zk_vk_from_json", "zk_proof_from_json", "zk_vk_free",
-    "zk_domain_size", "zk_ctx_create", "zk_ctx_destroy",
+    "zk_domain_size", "zk_ctx_create", "zk_ctx_create_sized", "zk_ctx_destroy",
     "zk_prove", "zk_prove_timed", "zk_prove_partial", "zk_prove_partial_timed", "zk_prove_combine", "zk_prove_submit", "zk_prove_collect", "zk_proof_to_json",
     "zk_prove_batch", "zk_prove_batch_submit", "zk_prove_batch_submit_resident", "zk_prove_batch_collect",
     "zk_wplan_create", "zk_wplan_solve", "zk_wplan_free", "zk_dev_alloc", "zk_dev_free", "zk_dev_upload", "zk_dev_download",
@@ -90,6 +92,9 @@ def load_library(path=None):
     L.zk_ctx_partials_device.restype = C.c_void_p
     L.zk_chain_device.restype = C.c_void_p
     L.zk_h_device.restype = C.c_void_p
+    L.zk_abi_version.restype = C.c_uint32
+    if L.zk_abi_version() != ABI_VERSION:                # struct layouts of this binding (ZkConfig ...) are those of include/zkhip.h ZK_ABI_VERSION
+        raise ImportError("%s has ABI version %d, this binding was written for %d" % (path, L.zk_abi_version(), ABI_VERSION))
     _lib, _lib_path_loaded = L, path
     return L
 
@@ -311,8 +316,8 @@ class ProverContext:
         a, b, c = _csr_structs(r1cs, self._keep)
         cfg = ZkConfig(multi_exp_c, device, shard_rank, shard_count, max_batch, 1 if one_stream else 0)
         h = C.c_void_p()
-        _check(lib.zk_ctx_create(pk._h, C.byref(a), C.byref(b), C.byref(c), C.c_uint32(r1cs.nC), C.c_uint32(r1cs.nIn),
-                                 C.c_uint32(r1cs.V), C.byref(cfg), C.byref(h)))
+        _check(lib.zk_ctx_create_sized(pk._h, C.byref(a), C.byref(b), C.byref(c), C.c_uint32(r1cs.nC), C.c_uint32(r1cs.nIn),
+                                       C.c_uint32(r1cs.V), C.byref(cfg), C.c_size_t(C.sizeof(cfg)), C.byref(h)))
         self._h = h
         self._keep = []     # the context copied everything it needs
         self.shard_count = shard_count

@@ -226,7 +226,7 @@ inline void ensure_context(ProverContextT &context, const ProtoboardT &pb) {
     const zk_csr a = f.a(), b = f.b(), c = f.c();
     zk_config cfg{context.config.multi_exp_c, hip_device(), 0, 1, 1, ZK_SCHED_OVERLAP};
     zk_ctx *h = nullptr;
-    zk_check(zk_ctx_create(context.provingKey.get(), &a, &b, &c, f.nC, f.nIn, f.V, &cfg, &h));
+    zk_check(zk_ctx_create_sized(context.provingKey.get(), &a, &b, &c, f.nC, f.nIn, f.V, &cfg, sizeof(cfg), &h));   // the size this translation unit was compiled with
     context.ctx.reset(h, zk_ctx_destroy);
 }
 // pb.values (Fr[V + 1], ONE at index 0) as the C ABI wants it
@@ -250,13 +250,40 @@ inline const std::shared_ptr<DomainT> get_domain(ProtoboardT &pb, const ProvingK
     return std::make_shared<DomainT>(DomainT{zk_domain_size((uint32_t)cs.num_constraints(), (uint32_t)cs.num_inputs())});
 }
 
+// The reference's prover reports its phases through libff::enter_block / leave_block (tcc:454-544) unless
+// libff::inhibit_profiling_info is set.  Here the same block names are printed after the proof, with the GPU time of each
+// phase (zk_timings), when this flag is cleared -- it starts out set: the phases overlap on the device, so the lines are a
+// report, not a nesting trace, and a drop-in caller's stdout stays what it was.  ZK_PROFILING_INFO=1 in the environment
+// clears it too (read once).
+inline bool &inhibit_profiling_info() {
+    static bool inhibit = !(std::getenv("ZK_PROFILING_INFO") && std::getenv("ZK_PROFILING_INFO")[0] == '1');
+    return inhibit;
+}
+namespace detail {
+inline void print_prover_blocks(const zk_timings &t, std::FILE *f = stdout) {
+    const double total = (double)t.h2d_witness + t.gpu_total + t.host_finish;
+    auto leave = [&](int indent, const char *name, double ms) { std::fprintf(f, "%*s(leave) %-46s [%0.4fs]\n", 2 * indent, "", name, ms * 1e-3); };
+    std::fprintf(f, "(enter) Call to r1cs_gg_ppzksnark_zok_prover\n");
+    leave(1, "Compute the polynomial H", t.compute_h);                              // tcc:460-475
+    std::fprintf(f, "  (enter) Compute the proof\n");                              // tcc:485
+    leave(2, "Compute evaluation to A-query", t.a_query);                           // tcc:487-496
+    leave(2, "Compute evaluation to B-query", t.b_query);                           // tcc:498-507
+    leave(2, "Compute evaluation to H-query", t.h_query);                           // tcc:509-519
+    leave(2, "Compute evaluation to L-query", t.l_query);                           // tcc:521-531
+    leave(1, "Compute the proof", (double)t.gpu_total - t.compute_h > 0 ? (double)t.gpu_total + t.host_finish : (double)t.host_finish);   // tcc:542
+    leave(0, "Call to r1cs_gg_ppzksnark_zok_prover", total);                        // tcc:544
+    std::fprintf(f, "* G1 elements in proof: 2\n* G2 elements in proof: 1\n* Proof size in bits: %d\n", 2 * 256 + 512);   // proof.print_size(), tcc:547 (uncompressed affine coordinates here)
+}
+}  // namespace detail
+
 // prove (src/stubs.cpp:42-47): proof JSON of src/export.cpp:99-121
 namespace detail {
 inline std::string prove_const(ProverContextT &context, const ProtoboardT &pb) {
     ensure_context(context, pb);
     const Witness w(pb);                                            // ONE at index 0 (tcc:492-493)
     zk_proof proof;
-    zk_check(zk_prove(context.ctx.get(), w.ptr, w.canonical, &proof));
+    if (inhibit_profiling_info()) zk_check(zk_prove(context.ctx.get(), w.ptr, w.canonical, &proof));
+    else { zk_timings t; zk_check(zk_prove_timed(context.ctx.get(), w.ptr, w.canonical, &proof, &t)); print_prover_blocks(t); }
     const uint32_t nIn = (uint32_t)pb.constraint_system.num_inputs();
     size_t len = 0;
     zk_proof_to_json(&proof, w.ptr + 4, nIn, w.canonical, nullptr, 0, &len);
@@ -282,7 +309,7 @@ class ProverPipeline {
         zk_config cfg{config.multi_exp_c, hip_device(), 0, 1, 1, ZK_SCHED_OVERLAP};
         for (unsigned i = 0; i < (contexts ? contexts : 1); i++) {
             zk_ctx *h = nullptr;
-            zk_check(zk_ctx_create(pk.get(), &a, &b, &c, f.nC, f.nIn, f.V, &cfg, &h));
+            zk_check(zk_ctx_create_sized(pk.get(), &a, &b, &c, f.nC, f.nIn, f.V, &cfg, sizeof(cfg), &h));
             slots_.emplace_back();
             slots_.back().ctx.reset(h, zk_ctx_destroy);
         }

@@ -52,7 +52,15 @@ extern "C" {
 #define ZK_CODEC_ALT_BN128 0   /* upstream libff alt_bn128 stream layout */
 #define ZK_CODEC_MCL_BN128 1   /* the reference's default curve build (CMakeLists.txt:47-54); its element encoding lives in the
                                   absent libff fork and is INFERRED (same flag + raw Montgomery coordinates as ALT_BN128):
-                                  parity unpinned -- the reference holds no key file (open risk) */
+                                  parity unpinned -- the reference holds no key file (open risk).
+                                  TODAY THE TWO CODEC VALUES READ AND WRITE BYTE-IDENTICAL FILES: the value is validated and
+                                  recorded, nothing else; a verified mcl layout would change the point reader / writer only */
+
+/* ABI version of this header: bumped whenever a struct below changes layout or a function changes signature.
+ * 3: zk_config = {multi_exp_c, device, shard_rank, shard_count, max_batch, schedule} (24 bytes; rounds 1-2 had 16 / 24).
+ * A client checks zk_abi_version() == ZK_ABI_VERSION once after loading the library, or passes the size of the zk_config
+ * it was compiled with to zk_ctx_create_sized (members it does not know read as 0 = their defaults). */
+#define ZK_ABI_VERSION 3
 
 typedef struct zk_pk zk_pk;
 typedef struct zk_vk zk_vk;
@@ -109,6 +117,7 @@ typedef struct {
 
 /* ---- library / device */
 const char *zk_version(void);
+uint32_t zk_abi_version(void);
 const char *zk_strerror(int code);
 const char *zk_last_error(void);
 int zk_device_count(int *count);
@@ -156,6 +165,8 @@ void zk_vk_free(zk_vk *vk);
 uint32_t zk_domain_size(uint32_t nC, uint32_t nIn);                      /* src/stubs.cpp:49-65 */
 int zk_ctx_create(const zk_pk *pk, const zk_csr *A, const zk_csr *B, const zk_csr *C,
                   uint32_t nC, uint32_t nIn, uint32_t V, const zk_config *cfg, zk_ctx **out);
+int zk_ctx_create_sized(const zk_pk *pk, const zk_csr *A, const zk_csr *B, const zk_csr *C,
+                        uint32_t nC, uint32_t nIn, uint32_t V, const zk_config *cfg, size_t cfg_size, zk_ctx **out);
 void zk_ctx_destroy(zk_ctx *ctx);
 
 /* witness: (V + 1) x 4 u64, ONE at index 0 (pb.values layout), Montgomery unless canonical != 0 */

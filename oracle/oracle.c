@@ -363,6 +363,76 @@ int orc_keygen(const orc_r1cs *cs, uint64_t seed, orc_pk **pk_out, orc_vk **vk_o
     return orc_keygen_explicit(cs, toxic, pk_out, vk_out);
 }
 
+static void g1_canon(const g1a_t *p, uint64_t x[4], uint64_t y[4], uint32_t *inf);
+static void g2_canon(const g2a_t *p, uint64_t xc0[4], uint64_t xc1[4], uint64_t yc0[4], uint64_t yc1[4], uint32_t *inf);
+/* =========================================================== closed form from the toxic waste
+ * The no-ZK proof straight from the definitions (the reference's comments at tcc:533-540 with the key elements of
+ * tcc:326-350 and the QAP of SURVEY Appendix A.3 / A.4):
+ *   A = (alpha + sum_i w_i A_i(t)) G1,  B = (beta + sum_i w_i B_i(t)) G2,
+ *   C = ((sum_{i>nIn} w_i (beta A_i + alpha B_i + C_i)(t) + A(t) B(t) - C(t)) / delta) G1     (H(t) Z(t) = A(t) B(t) - C(t)).
+ * O(nnz) field operations and THREE plain double-and-add scalar multiplications: no multi-exponentiation, no transform,
+ * no proving key, no stream codec is touched -- an independent pin of orc_prove and of the HIP path. */
+int orc_proof_from_trapdoor(const orc_r1cs *cs, const uint64_t *witness, const uint64_t toxic[20], orc_proof *out) {
+    const fe_t *w = (const fe_t *)witness;
+    uint32_t nC = cs->nC, nIn = cs->nIn;
+    uint32_t m = orc_domain_size(nC, nIn), logm = ilog2(m);
+    fe_t t, alpha, beta, delta;
+    fr_to_mont(&t, (const fe_t *)(toxic + 0)); fr_to_mont(&alpha, (const fe_t *)(toxic + 4)); fr_to_mont(&beta, (const fe_t *)(toxic + 8));
+    fr_to_mont(&delta, (const fe_t *)(toxic + 16));
+    fe_t om, Zt, mfe, wi = fr_ONE;
+    domain_omega(&om, logm);
+    fr_pow_u64(&Zt, &t, m); fr_sub(&Zt, &Zt, &fr_ONE);
+    fr_set_u64(&mfe, m);
+    fe_t *u = (fe_t *)malloc(sizeof(fe_t) * m), *den = (fe_t *)malloc(sizeof(fe_t) * m);
+    if (!u || !den) { free(u); free(den); return -1; }
+    for (uint32_t j = 0; j < m; j++) {                      /* u_j = omega^j Z(t) / (m (t - omega^j)) */
+        fe_t d; fr_sub(&d, &t, &wi); fr_mul(&den[j], &d, &mfe);
+        fr_mul(&u[j], &wi, &Zt); fr_mul(&wi, &wi, &om);
+    }
+    fr_batch_inv(den, m);
+    for (uint32_t j = 0; j < m; j++) fr_mul(&u[j], &u[j], &den[j]);
+    free(den);
+    const orc_csr *Ms[3] = {&cs->A, &cs->B, &cs->C};
+    fe_t S[3], P[3];                                        /* sums over all variables / over the public ones (i <= nIn) */
+    for (int q = 0; q < 3; q++) {
+        fe_t tot = {{0, 0, 0, 0}}, pub = {{0, 0, 0, 0}};
+        for (uint32_t j = 0; j < nC; j++) {
+            fe_t row = {{0, 0, 0, 0}}, prow = {{0, 0, 0, 0}}, v;
+            for (uint32_t k = Ms[q]->row_ptr[j]; k < Ms[q]->row_ptr[j + 1]; k++) {
+                fr_mul(&v, (const fe_t *)(Ms[q]->coeff + 4 * (size_t)k), &w[Ms[q]->col[k]]);
+                fr_add(&row, &row, &v);
+                if (Ms[q]->col[k] <= nIn) fr_add(&prow, &prow, &v);
+            }
+            fr_mul(&v, &row, &u[j]); fr_add(&tot, &tot, &v);
+            fr_mul(&v, &prow, &u[j]); fr_add(&pub, &pub, &v);
+        }
+        S[q] = tot; P[q] = pub;
+    }
+    for (uint32_t i = 0; i <= nIn; i++) {                   /* input-consistency rows of A */
+        fe_t v; fr_mul(&v, &u[nC + i], &w[i]);
+        fr_add(&S[0], &S[0], &v); fr_add(&P[0], &P[0], &v);
+    }
+    free(u);
+    fe_t a, b, c, x, y, di;
+    fr_add(&a, &alpha, &S[0]); fr_add(&b, &beta, &S[1]);
+    fr_sub(&x, &S[0], &P[0]); fr_mul(&c, &beta, &x);
+    fr_sub(&x, &S[1], &P[1]); fr_mul(&y, &alpha, &x); fr_add(&c, &c, &y);
+    fr_sub(&x, &S[2], &P[2]); fr_add(&c, &c, &x);
+    fr_mul(&y, &S[0], &S[1]); fr_add(&c, &c, &y); fr_sub(&c, &c, &S[2]);
+    fr_inv(&di, &delta); fr_mul(&c, &c, &di);
+    fe_t ka, kb, kc;
+    fr_from_mont(&ka, &a); fr_from_mont(&kb, &b); fr_from_mont(&kc, &c);
+    g1j_t g1, ja, jc; g2j_t g2, jb; g1a_t ra, rc; g2a_t rb;
+    g1_generator(&g1); g2_generator(&g2);
+    g1_mul_scalar(&ja, &g1, ka.l); g2_mul_scalar(&jb, &g2, kb.l); g1_mul_scalar(&jc, &g1, kc.l);
+    g1_to_aff(&ra, &ja); g2_to_aff(&rb, &jb); g1_to_aff(&rc, &jc);
+    memset(out, 0, sizeof *out);
+    g1_canon(&ra, out->a_x, out->a_y, &out->a_inf);
+    g2_canon(&rb, out->b_x_c0, out->b_x_c1, out->b_y_c0, out->b_y_c1, &out->b_inf);
+    g1_canon(&rc, out->c_x, out->c_y, &out->c_inf);
+    return 0;
+}
+
 /* =========================================================== .raw stream (tcc:108-143, utils.hpp:166-185) */
 /* upstream libff encoding under BINARY_OUTPUT + MONTGOMERY_OUTPUT + NO_PT_COMPRESSION:
  * point = ASCII '0'/'1' infinity flag, then raw Montgomery limbs of X, Y (G2: X.c0 X.c1 Y.c0 Y.c1);

@@ -98,6 +98,9 @@ size_t orc_vk_to_json(const orc_vk *, char *buf, size_t cap);     /* src/export.
 /* phase_seconds[6]: H polynomial, A-query, B-query, H-query, L-query, final (names of tcc:460-542) */
 int orc_prove(const orc_pk *, const orc_r1cs *cs, const uint64_t *witness, unsigned msm_c,
               orc_proof *out, double phase_seconds[6]);
+/* the same proof in closed form from the toxic waste (t, alpha, beta, gamma, delta canonical, as orc_keygen_explicit takes
+ * them): three scalar multiplications, no multi-exponentiation / transform / key involved (tcc:533-540 comments) */
+int orc_proof_from_trapdoor(const orc_r1cs *cs, const uint64_t *witness, const uint64_t toxic_canon[20], orc_proof *out);
 /* inputs: nIn Montgomery Fr elements (witness[1..nIn]); returns bytes needed (excluding NUL) */
 size_t orc_proof_to_json(const orc_proof *, const uint64_t *inputs, uint32_t nIn, char *buf, size_t cap);
 int orc_num_threads(void);

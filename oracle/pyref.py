@@ -297,6 +297,49 @@ def prove(pk, r1cs, w):
     return g1_add(pk["alpha_g1"], At), g2_add(pk["beta_g2"], Bt), g1_add(Ht, Lt)
 
 
+def proof_from_trapdoor(r1cs, w, t, alpha, beta, gamma, delta, g1=G1_GEN, g2=G2_GEN):
+    """The no-ZK proof in closed form from the toxic waste, straight from the definitions the reference's comments give
+    (tcc:533-540 with the key elements of tcc:326-350 and the QAP of SURVEY Appendix A.3/A.4):
+        A = (alpha + sum_i w_i A_i(t)) G1,   B = (beta + sum_i w_i B_i(t)) G2,
+        C = ((sum_{i>nIn} w_i (beta A_i + alpha B_i + C_i)(t) + A(t) B(t) - C(t)) / delta) G1,
+    where A(t) = sum_i w_i A_i(t) etc. and H(t) Z(t) = A(t) B(t) - C(t).  Three scalar multiplications, O(nnz) field
+    operations: no multi-exponentiation, no transform, no key, no codec -- an independent pin of prove() / the C oracle /
+    the HIP path for any (r1cs, witness, toxic waste).  (gamma only enters the verification key.)"""
+    nC, nIn, V, A, B, C = r1cs
+    m = domain_size(nC, nIn)
+    om = omega(m)
+    Zt = (pow(t, m, R) - 1) % R
+    # Lagrange basis at t, u_j = omega^j Z(t) / (m (t - omega^j)): one batch inversion
+    wj, den, pre, acc = 1, [], [], 1
+    for j in range(m):
+        d = m * (t - wj) % R
+        den.append(d); pre.append(acc); acc = acc * d % R
+        wj = wj * om % R
+    inv = pow(acc, -1, R)
+    u = [0] * m
+    wpow = pow(om, m - 1, R); omi = pow(om, -1, R)
+    for j in range(m - 1, -1, -1):
+        u[j] = wpow * Zt % R * (inv * pre[j] % R) % R
+        inv = inv * den[j] % R
+        wpow = wpow * omi % R
+    def evaluate(rows):
+        """(sum over all variables, sum over the public ones i <= nIn) of w_i M_i(t), M_i(t) = sum_j M_ji u_j"""
+        tot = pub = 0
+        for j, row in enumerate(rows):
+            for i, c in row:
+                v = c * w[i] % R * u[j]
+                tot += v
+                if i <= nIn: pub += v
+        return tot % R, pub % R
+    SA, pA = evaluate(A); SB, pB = evaluate(B); SC, pC = evaluate(C)
+    for i in range(nIn + 1):                                   # input-consistency rows of A (Appendix A.3 step 1)
+        v = u[nC + i] * w[i] % R
+        SA = (SA + v) % R; pA = (pA + v) % R
+    priv = (beta * (SA - pA) + alpha * (SB - pB) + (SC - pC)) % R
+    c = (priv + SA * SB - SC) * pow(delta, -1, R) % R
+    return g1_mul(g1, (alpha + SA) % R), g2_mul(g2, (beta + SB) % R), g1_mul(g1, c)
+
+
 def keygen(r1cs, t, alpha, beta, gamma, delta, g1=G1_GEN, g2=G2_GEN):
     """Generator tcc:277-449 + Appendix A.4 + nozk conversion hpp:209-233, toxic waste given explicitly."""
     nC, nIn, V, A, B, C = r1cs

@@ -209,6 +209,33 @@ def read_raw(path):
     return PK(pk)
 
 
+def _proof_json(proof, r, w):
+    buf = C.create_string_buffer(4096 + 80 * r.nIn)
+    inputs = np.ascontiguousarray(w[1:1 + r.nIn])
+    n = lib().orc_proof_to_json(C.byref(proof), _p64(inputs) if r.nIn else None, C.c_uint32(r.nIn), buf, C.c_size_t(len(buf)))
+    return buf.raw[:n].decode()
+
+
+def toxic_from_seed(seed):
+    """the toxic waste (t, alpha, beta, gamma, delta) orc_keygen / zk_keygen derive from a seed: 5 x (4 SplitMix64 draws mod r)"""
+    from ethsnarks_amd.r1cs import SplitMix64
+    rng = SplitMix64(seed)
+    return [rng.fr() for _ in range(5)]
+
+
+def proof_from_trapdoor(r, w_mont, toxic):
+    """proof JSON in closed form from the toxic waste (ints): three scalar multiplications, no MSM / NTT / key (oracle.c)"""
+    from ethsnarks_amd.fields import ints_to_limbs
+    k = r1cs_struct(r)
+    w = np.ascontiguousarray(w_mont, dtype=np.uint64)
+    t = np.ascontiguousarray(ints_to_limbs(toxic)).reshape(-1)
+    proof = OrcProof()
+    rc = lib().orc_proof_from_trapdoor(C.byref(k.struct), _p64(w), _p64(t), C.byref(proof))
+    if rc != 0:
+        raise RuntimeError("orc_proof_from_trapdoor failed: %d" % rc)
+    return _proof_json(proof, r, w)
+
+
 def prove(pk, r, w_mont, c=0):
     """returns (proof_json, phase_seconds[6])"""
     k = r1cs_struct(r)
@@ -218,7 +245,4 @@ def prove(pk, r, w_mont, c=0):
     rc = lib().orc_prove(pk.h, C.byref(k.struct), _p64(w), C.c_uint(c), C.byref(proof), ph)
     if rc != 0:
         raise RuntimeError("orc_prove failed: %d" % rc)
-    buf = C.create_string_buffer(4096 + 80 * r.nIn)
-    inputs = np.ascontiguousarray(w[1:1 + r.nIn])
-    n = lib().orc_proof_to_json(C.byref(proof), _p64(inputs) if r.nIn else None, C.c_uint32(r.nIn), buf, C.c_size_t(len(buf)))
-    return buf.raw[:n].decode(), list(ph)
+    return _proof_json(proof, r, w), list(ph)

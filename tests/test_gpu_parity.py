@@ -204,6 +204,7 @@ def test_config1_mimc_hash_preimage_11_words(hip, oracle):
     got = hip.prove(ctx, wm)
     expect, _ = oracle.prove(pk_o, r, wm)
     assert got == expect
+    assert got == oracle.proof_from_trapdoor(r, wm, oracle.toxic_from_seed(11))     # closed form: no MSM / NTT / key / codec involved
     assert hip.stub_verify(vk.to_json(), got)
     assert pyref.verify(json.loads(vk.to_json()), json.loads(got))
     bad = json.loads(got); bad["A"], bad["C"] = bad["C"], bad["A"]
@@ -250,6 +251,7 @@ def test_config4_merkle_membership_depth29(hip, oracle):
     got = hip.prove(ctx, wm)
     expect, _ = oracle.prove(pk_o, r, wm)
     assert got == expect
+    assert got == oracle.proof_from_trapdoor(r, wm, oracle.toxic_from_seed(29))     # closed form from the toxic waste
     proof = json.loads(got)
     assert int(proof["input"][0], 16) == root
     assert pyref.verify(json.loads(vk.to_json()), proof)
@@ -257,7 +259,7 @@ def test_config4_merkle_membership_depth29(hip, oracle):
     # a different leaf position: address bits / selector products are 0/1-valued witness entries
     r2, w2, _ = G.merkle_membership_circuit(29, leaf=12345, address=0x15555555, path=[G.merkle_unique(d, 7) for d in range(29)])
     expect2, _ = oracle.prove(pk_o, r2, F.fr_to_mont(w2))                   # same constraint system, same key
-    assert hip.prove(ctx, F.fr_to_mont(w2)) == expect2
+    assert hip.prove(ctx, F.fr_to_mont(w2)) == expect2 == oracle.proof_from_trapdoor(r2, F.fr_to_mont(w2), oracle.toxic_from_seed(29))
 
 
 @pytest.mark.parametrize("k", [1, 4, 16])
@@ -347,6 +349,7 @@ def test_config2_chain_2pow18_gpu_keygen(hip, oracle, tmp_path):
     ctx = hip.ProverContext(pk, r)
     expect, _ = oracle.prove(pk_o, r, wm)
     assert hip.prove(ctx, wm) == expect
+    assert expect == oracle.proof_from_trapdoor(r, wm, oracle.toxic_from_seed(18))  # closed form: independent of the .raw codec too
 
 
 def test_staged_upload_double_buffering(hip, oracle):
@@ -437,6 +440,7 @@ def test_config3_chain_2pow20_headline(hip, oracle):
     ctx.close()
     expect, _ = oracle.prove(oracle.pk_from_parts(pk.parts()), r, wm)
     assert got == expect
+    assert got == oracle.proof_from_trapdoor(r, wm, oracle.toxic_from_seed(R.SEED_DEFAULT))   # closed form from the toxic waste (tcc:533-540)
     shards = []
     for k in range(4):
         c = hip.ProverContext(pk, r, shard_rank=k, shard_count=4)
@@ -462,6 +466,7 @@ def test_config5_size_2pow22_sharded_over_eight(hip, oracle):
     assert hip.stub_verify(vk.to_json(), got)
     expect, _ = oracle.prove(oracle.pk_from_parts(pk.parts()), r, wm)        # the oracle at 2^22
     assert got == expect
+    assert got == oracle.proof_from_trapdoor(r, wm, oracle.toxic_from_seed(R.SEED_DEFAULT))   # closed form: O(nnz) field work + 3 scalar multiplications
     d = json.loads(got)
     d["input"][0] = d["input"][0][:-1] + ("0" if d["input"][0][-1] != "0" else "1")      # another public input
     assert not hip.stub_verify(vk.to_json(), json.dumps(d))

@@ -71,6 +71,32 @@ def test_oracle_matches_pyref_golden(oracle, case):
     assert proof_json == case["proof_json"]
 
 
+@pytest.mark.parametrize("case", golden_cases(), ids=lambda c: c["name"])
+def test_trapdoor_closed_form_equals_the_provers(oracle, case):
+    """The proof in closed form from the toxic waste (tcc:533-540 comments: A = (alpha + sum w_i A_i(t)) G1, ...): three scalar
+    multiplications, no multi-exponentiation / transform / key / codec.  pyref's and the C oracle's closed forms equal each
+    other and the golden proof both provers produce through the key."""
+    r, w, toxic = build_case(case)
+    A, B, C = pyref.proof_from_trapdoor(r.as_pyref(), w, *toxic)
+    js = pyref.proof_to_json(A, B, C, w[1:1 + r.nIn])
+    assert js == case["proof_json"]
+    assert oracle.proof_from_trapdoor(r, F.fr_to_mont(w), toxic) == case["proof_json"]
+
+
+def test_trapdoor_closed_form_on_seeded_keys_and_real_circuits(oracle):
+    """seeded keys (what the GPU tests and bench.py use) and a circuit with general coefficients, unused variables and zero rows"""
+    from ethsnarks_amd import gadgets as G
+    for r, w, seed in [R.random_r1cs(200, 3, seed=12) + (21,), R.synthetic_chain((1 << 9) - 2, 1) + (R.SEED_DEFAULT,),
+                       G.mimc_preimage_circuit(1)[:2] + (9,)]:
+        wm = F.fr_to_mont(w)
+        pk, _ = oracle.keygen(r, seed=seed)
+        js, _ = oracle.prove(pk, r, wm)
+        assert oracle.proof_from_trapdoor(r, wm, oracle.toxic_from_seed(seed)) == js
+    # an unsatisfying witness has no proof through the key (degree check) and the closed form is not it either: nothing to compare,
+    # but another toxic waste must give another proof
+    assert oracle.proof_from_trapdoor(r, wm, oracle.toxic_from_seed(seed + 1)) != js
+
+
 def test_oracle_proofs_verify_and_witness_map_matches(oracle):
     r, w = R.random_r1cs(24, 2, seed=77)
     wm = F.fr_to_mont(w)
