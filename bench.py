@@ -5,10 +5,13 @@
 
 A "step" is one full proof (witness -> QAP coefficients -> four multi-exponentiations -> proof) of the
 synthetic chain R1CS of SURVEY 8(d) with nC = 2^20 - 2 constraints (domain m = 2^20 exactly), nIn = 1,
-on a real proving key produced by this library's GPU key generator (seeded toxic waste).  Key, constraint
-system AND witness are resident in HBM when the timed region starts (`value`); the rate with the witness
-handed over as a host buffer -- its 33.5 MB upload inside the timed region -- is measured on a short
-second leg and reported under "host_witness" (never as `value`).
+on a real proving key produced by this library's GPU key generator (seeded toxic waste).  Key and constraint
+system are resident in HBM; the WITNESS lies in pinned host memory when the timed region starts and every proof's
+33.5 MB H2D copy is inside it (SURVEY 8(d)'s metric: `value`; the prover pipeline copies a context's next witness on
+its copy stream while the current proof runs: zk_prove_stage_pinned / zk_prove_submit_staged).  The other ways to
+hand a witness over are timed on legs of the same length and reported under "witness_modes": resident in HBM (the
+PCIe-free rate, never `value`), pinned with the copy on the proof's own stream (zk_prove_submit_pinned), and a
+pageable host buffer with and without the double buffering (zk_prove_submit / zk_prove_stage).
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): proofs are independent units, so the
 headline leg runs one prover per GPU with no data-path collective ("weak" scaling, value = all proofs of
@@ -36,6 +39,15 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+WITNESS_MODES = ["host", "resident", "host-direct", "host-pageable", "host-pageable-staged"]
+WITNESS_NOTE = {
+    "host": "pinned host buffer (SURVEY 8(d)), every witness's H2D copy inside the timed region, double-buffered: a context's NEXT witness is copied "
+            "on the copy stream while its current proof runs (zk_prove_stage_pinned / zk_prove_submit_staged)",
+    "resident": "resident in HBM when the timed region starts (no PCIe traffic)",
+    "host-direct": "pinned host buffer, one zk_prove_submit_pinned per proof: the H2D copy heads the proof's own stream (on its critical path)",
+    "host-pageable": "pageable host buffer: plain zk_prove_submit copies it into pinned staging memory, then H2D, both inside the timed region",
+    "host-pageable-staged": "pageable host buffer, double-buffered: zk_prove_stage copies a context's NEXT witness (memcpy into pinned staging + H2D) while its current proof runs",
+}
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 MAD_LANE_OPS_PER_CLK_CU = 43.4  # measured v_mad_u64_u32 rate, tools/microbench (profiles/r01_microbench.txt)
 MADS_PER_G2_MADD = 6 * 400 + 2 * 272 + 656   # = 3600: 6 Fq2 products (2 x (2 x 64 + 72)), 2 Fq2 squarings (2 x 136), one 2-term Fq2 dot product (2 x (4 x 64 + 72))
@@ -59,9 +71,12 @@ def main():
     ap.add_argument("--batch", type=int, default=1,
                     help="proofs per launch sequence (zk_prove_batch): a step then proves this many witnesses of the circuit; "
                          "what the latency-sized workloads need (one small proof alone is ~50 launches of latency-bound kernels)")
-    ap.add_argument("--witness", choices=["resident", "host"], default="resident",
-                    help="where the witness lives when the timed region starts (`value` is quoted on resident)")
-    ap.add_argument("--no-stage", action="store_true", help="host witness: plain zk_prove_submit instead of zk_prove_stage / zk_prove_submit_staged (double-buffered upload)")
+    ap.add_argument("--witness", choices=WITNESS_MODES, default="host",
+                    help="where the witness lives when the timed region starts.  host (the default, SURVEY 8(d)): pinned host memory, "
+                         "H2D inside the timed region, double-buffered (zk_prove_stage_pinned / zk_prove_submit_staged); resident: already in HBM; "
+                         "host-direct: pinned, one zk_prove_submit_pinned per proof; host-pageable: pageable buffer through plain zk_prove_submit; "
+                         "host-pageable-staged: zk_prove_stage")
+    ap.add_argument("--batch-identical", action="store_true", help="--batch k: k copies of ONE witness instead of k different ones (shows what identical digits / gather addresses are worth)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary legs (host-witness rate, sharded legs, kernel sum)")
     ap.add_argument("--cpu-1t-logm", type=int, default=16, help="size of the one-thread CPU sample (a full 2^20 proof takes a minute on one core)")
@@ -120,6 +135,37 @@ def main():
     nC, m = r1cs.nC, r1cs.domain_size
     logm = m.bit_length() - 1
 
+    # which GPU every rank really sits on: gathered once, asserted distinct, reported in the line (SCALE can check it)
+    rccl_info = None
+    if world > 1:
+        mine = "%s|%s" % (os.uname().nodename, P.device_pci_bus_id(local_rank))
+        ids = [None] * world
+        dist.all_gather_object(ids, mine)
+        rccl_info = {"world": world, "backend": dist.get_backend(), "device_ids": ids}
+        if not rehearse:
+            assert len(set(ids)) == world, "ranks share a GPU: %r" % (ids,)
+
+    def batch_witnesses(r1cs, wm, kb):
+        """kb x (V + 1) x 4: the witnesses of one launch sequence.  kb DISTINCT satisfying witnesses of the circuit (other seeds /
+        leaves / preimages: identical witnesses would share digits, bucket occupancy and gather addresses); --batch-identical tiles one"""
+        first = np.ascontiguousarray(wm).reshape(1, -1, 4)
+        if kb == 1:
+            return first
+        if args.batch_identical:
+            return np.ascontiguousarray(np.tile(first, (kb, 1, 1)))
+        out = [first[0]]
+        for p in range(1, kb):
+            if args.workload == "chain":
+                _, w = R.synthetic_chain(r1cs.nC, 1, seed=R.SEED_DEFAULT + p)
+            else:
+                from ethsnarks_amd import gadgets as G
+                if args.workload == "merkle29":
+                    _, w, _ = G.merkle_membership_circuit(29, leaf=1000 + p, address=(0x2545F491 * p) & ((1 << 29) - 1), path=[G.merkle_unique(d, p) for d in range(29)])
+                else:
+                    _, w, _ = G.mimc_preimage_circuit(11, seed=7 + p)
+            out.append(F.fr_to_mont(w))
+        return np.ascontiguousarray(np.stack(out))
+
     def sync():
         torch.cuda.synchronize()
         if dist is not None:
@@ -136,12 +182,16 @@ def main():
         ctxs = [P.ProverContext(pk, r1cs, multi_exp_c=args.multi_exp_c, device=local_rank,
                                 shard_rank=rank if shard else 0, shard_count=world if shard else 1, max_batch=kb, one_stream=args.one_stream)
                 for _ in range(max(1, args.inflight))]
-        wmk = np.ascontiguousarray(np.tile(np.ascontiguousarray(wm).reshape(1, -1), (kb, 1)))     # the batch: kb witnesses, contiguous
+        wmk = batch_witnesses(r1cs, wm, kb)                        # the batch: kb DISTINCT satisfying witnesses of the circuit, contiguous
         d_w = torch.from_numpy(wmk.view(np.int64).copy()).cuda() if witness == "resident" else None
+        pinned = None
+        if witness in ("host", "host-direct"):                      # the witness lies in pinned host memory
+            pinned = P.PinnedBuffer(wmk.nbytes)
+            pinned.array[:] = wmk.reshape(-1)
         sharded = [ShardedProver(c, dist, torch.device("cuda", local_rank)) for c in ctxs] if (shard and not gloo) else None
         gather_buf = torch.empty((world, 640), dtype=torch.uint8) if (shard and gloo) else None
         acc_b, pending, state = [], [], {"t": {}}
-        use_stage = (witness == "host") and not shard and not args.no_stage
+        use_stage = witness in ("host", "host-pageable-staged") and not shard
         staged = [False] * len(ctxs)
 
         def finish(slot):
@@ -161,7 +211,7 @@ def main():
             state["t"] = tm
             acc_b.append(tm["acc_b"])
             all_acc_b.append(tm["acc_b"])
-            return P.proof_to_json(proof, wm[1:1 + r1cs.nIn])
+            return P.proof_to_json(proof, wmk[kb - 1].reshape(-1, 4)[1:1 + r1cs.nIn])
 
         def run(nsteps):
             js = None
@@ -169,22 +219,29 @@ def main():
                 if len(pending) == len(ctxs):
                     js = finish(pending.pop(0))
                 slot = i % len(ctxs)
-                if d_w is None and use_stage:
+                if use_stage:
                     # host witness, double-buffered upload: this context's NEXT witness was staged while its previous proof ran
                     if staged[slot]:
                         ctxs[slot].submit_staged()
+                    elif pinned is not None:
+                        ctxs[slot].submit_pinned(pinned, k=kb)
                     elif kb > 1:
                         ctxs[slot].submit_batch(wmk, k=kb)
                     else:
-                        ctxs[slot].submit(wm)
-                    ctxs[slot].stage(wmk.reshape(kb, -1, 4) if kb > 1 else wm)
+                        ctxs[slot].submit(wmk[0])
+                    if pinned is not None:
+                        ctxs[slot].stage_pinned(pinned, k=kb)
+                    else:
+                        ctxs[slot].stage(wmk.reshape(kb, -1, 4) if kb > 1 else wmk[0])
                     staged[slot] = True
+                elif pinned is not None:
+                    ctxs[slot].submit_pinned(pinned, k=kb)
                 elif kb > 1:
                     ctxs[slot].submit_batch(wmk, device_ptr=d_w.data_ptr() if d_w is not None else None, k=kb)
                 elif d_w is not None:
                     ctxs[slot].submit_resident(d_w.data_ptr())
                 else:
-                    ctxs[slot].submit(wm)
+                    ctxs[slot].submit(wmk[0])
                 pending.append(slot)
             while pending:
                 js = finish(pending.pop(0))
@@ -210,7 +267,7 @@ def main():
         if rank == 0 and not args.no_extras and not shard and kb == 1:
             # one more (untimed) proof with every launch bracketed by HIP events: sum of kernel durations per proof
             P.profile_begin()
-            ctxs[0].submit_resident(d_w.data_ptr()) if d_w is not None else ctxs[0].submit(wm)
+            ctxs[0].submit_resident(d_w.data_ptr()) if d_w is not None else ctxs[0].submit(wmk[0])
             _, t_alone = ctxs[0].collect()
             all_acc_b.append(t_alone["acc_b"])
             s_ms, n_l, per = P.profile_end()
@@ -219,6 +276,8 @@ def main():
                     "top": {k.strip("()"): {"calls": c, "ms": round(v, 3)} for k, (c, v) in top}}
         for c in ctxs:
             c.close()
+        if pinned is not None:
+            pinned.free()
         return {"value": proofs / elapsed, "elapsed": elapsed, "acc_b": list(acc_b), "timings": state["t"], "json": js,
                 "launches_per_proof": launches, "info": info, "kernel_sum": ksum}
 
@@ -235,22 +294,19 @@ def main():
             return
         if True:
             short = max(3, min(args.steps, 10))
-            try:
-                other = "host" if args.witness == "resident" else "resident"
-                h2 = run_leg(pk, r1cs, wm, shard, args.steps, args.warmup, other)      # same steps / warm-up as the headline leg
-                extras["%s_witness" % other] = {"value": round(h2["value"], 4), "unit": "proofs/s", "steps": args.steps,
-                                               "ms_per_step": round(1e3 * h2["elapsed"] / args.steps, 3),
-                                               "note": ("witness handed over as a host buffer: its copy into pinned memory and its %.1f MB H2D copy are inside the timed region (PCIe-inclusive rate); %s" % (32 * (r1cs.V + 1) / 1e6, "plain zk_prove_submit" if args.no_stage else "double-buffered: zk_prove_stage copies a context's next witness while its current proof runs"))
-                                                       if other == "host" else "witness resident in HBM"}
-                if other == "host" and not args.no_stage:            # the same leg with a plain zk_prove_submit per proof
-                    args.no_stage = True
-                    try:
-                        h3 = run_leg(pk, r1cs, wm, shard, args.steps, args.warmup, other)
-                        extras["host_witness"]["plain_submit"] = {"value": round(h3["value"], 4), "ms_per_step": round(1e3 * h3["elapsed"] / args.steps, 3)}
-                    finally:
-                        args.no_stage = False
-            except Exception as e:
-                extras["other_witness"] = {"error": repr(e)[:300]}
+            modes = {}
+            for other in WITNESS_MODES:                             # the other ways to hand the witness over, legs as long as the headline leg
+                if other == args.witness or shard:
+                    continue
+                try:
+                    h2 = run_leg(pk, r1cs, wm, shard, args.steps, args.warmup, other)
+                    modes[other] = {"value": round(h2["value"], 4), "unit": "proofs/s", "steps": args.steps,
+                                    "ms_per_step": round(1e3 * h2["elapsed"] / args.steps, 3), "witness": WITNESS_NOTE[other],
+                                    "same_proof": h2["json"] == js}
+                except Exception as e:
+                    modes[other] = {"error": repr(e)[:300]}
+            if modes:
+                extras["witness_modes"] = modes
             if world > 1 and mode == "replicas":
                 try:
                     s2 = run_leg(pk, r1cs, wm, True, short, 2, args.witness)
@@ -312,8 +368,9 @@ def main():
             "config": {"workload": workload,
                        "parallelism": ("msm-shard%d+allgather640B" % world) if shard else ("replicas%d" % world if world > 1 else "1gpu"),
                        "multi_exp_c": info["B"]["c"], "windows": W,
-                       "witness": "resident in HBM when the timed region starts" if args.witness == "resident" else "host buffer, H2D inside the timed region",
-                       "inflight": max(1, args.inflight), "schedule": "one stream per context" if args.one_stream else "overlap (five streams per context)", "proofs_per_step": max(1, args.batch) if not shard else 1, "device": devinfo},
+                       "witness": WITNESS_NOTE[args.witness], "witness_bytes_h2d_per_proof": 0 if args.witness == "resident" else 32 * (r1cs.V + 1),
+                       "inflight": max(1, args.inflight), "schedule": "one stream per context" if args.one_stream else "overlap (five streams per context)", "proofs_per_step": max(1, args.batch) if not shard else 1,
+                       "batch_witnesses": ("identical" if args.batch_identical else "distinct") if args.batch > 1 else None, "device": devinfo},
             "roofline": {"kernel": "k_msm_accumulate<G2, 1> (B-query bucket accumulation)", "bound": "hbm",
                          "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic, "traffic_source": traffic_src,
@@ -336,6 +393,8 @@ def main():
             "kernel_sum": head["kernel_sum"],
             "setup_s": {"circuit": round(t_circuit, 2), "gpu_keygen": round(t_keygen, 2)},
         }
+        if rccl_info is not None:
+            out["rccl"] = rccl_info
         if out["kernel_sum"] is not None:
             out["kernel_sum"]["note"] = ("HIP-event durations of every launch of one proof run alone, overlapping tails counted each; the timed steps keep %d proofs in flight, "
                                          "so ms_per_step (%.2f) is below this sum" % (max(1, args.inflight), out["ms_per_step"]))
@@ -353,7 +412,7 @@ def main():
             out.update(extras)
             out["extras_aborted"] = "secondary legs did not finish within %d s; headline unaffected" % args.extras_timeout
             print(json.dumps(out), flush=True)
-        os._exit(0)
+        os._exit(3)         # a process that has touched the GPU and bails out of a stalled collective must not look like a clean run
     watchdog = None
     if world > 1 and not args.no_extras:
         import threading

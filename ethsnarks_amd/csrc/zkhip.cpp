@@ -89,7 +89,13 @@ extern "C" int zk_device_info(int device, uint32_t *compute_units, uint32_t *clo
     if (name && name_cap) snprintf(name, name_cap, "%s", p.name);
     return ZK_OK;
 }
+extern "C" int zk_device_pci_bus_id(int device, char *buf, size_t cap) {
+    if (!buf || cap < 16) return fail_msg(ZK_ERR_ARG, "buffer too small");
+    if (hipDeviceGetPCIBusId(buf, (int)cap, device) != hipSuccess) return fail_msg(ZK_ERR_NODEVICE, "hipDeviceGetPCIBusId failed: no usable HIP device");
+    return ZK_OK;
+}
 #else
+extern "C" int zk_device_pci_bus_id(int, char *buf, size_t cap) { if (buf && cap) snprintf(buf, cap, "emulation"); return ZK_OK; }
 extern "C" uint64_t zk_launch_count(void) { return 0; }
 extern "C" int zk_profile_begin(void) { return ZK_OK; }
 extern "C" int zk_profile_end(float *s, uint32_t *n, char *buf, size_t cap) { if (s) *s = 0; if (n) *n = 0; if (buf && cap) buf[0] = 0; return ZK_OK; }
@@ -548,6 +554,7 @@ struct zk_ctx {
     DeviceTables *tables = nullptr;
     bool serial = false;
     bool in_flight = false;
+    bool awaiting_h = false;                   // the proof in flight was submitted without its H part (zk_prove_submit_defer_h): zk_prove_submit_h completes it
     uint32_t max_batch = 1, cur_batch = 1;     // proofs per launch sequence: capacity, and of the proof(s) in flight
     uint32_t nC = 0, nIn = 0, V = 0, m = 0, logm = 0;
     zk_config cfg{};
@@ -827,12 +834,14 @@ static int enqueue_h_from_chains(zk_ctx *c, const fe *a, const fe *b, const fe *
 
 // witness: a host buffer (staged through pinned memory, the reference's pb.values), or -- resident != 0 -- a buffer that
 // already lives in this device's memory (the caller keeps it untouched until the proof is collected)
-// resident: 0 = host buffer, 1 = device buffer of the caller, 2 = staged earlier (zk_prove_stage): already in d_w
+// resident: 0 = host buffer, 1 = device buffer of the caller, 2 = staged earlier (zk_prove_stage): already in d_w,
+//           3 = PINNED host buffer of the caller (zk_host_alloc / zk_host_register): copied from where it lies, no staging
 static int upload_witness(zk_ctx *c, const uint64_t *witness, int canonical, int resident = 0) {
     const size_t n = (size_t)(c->V + 1) * c->cur_batch;          // the witnesses of a batch are contiguous
     // a queued proof copies the caller's buffer into pinned memory (the caller may reuse it at once, the H2D copy is asynchronous);
     // a synchronous call hands the caller's buffer to the runtime, which pipelines its own staging with the DMA
-    const bool direct = !resident && c->latency_call && !c->env_no_direct_h2d;
+    const bool direct = resident == 3 || (!resident && c->latency_call && !c->env_no_direct_h2d);
+    if (resident == 3) resident = 0;
     if (!resident && !direct) memcpy(c->h_w, witness, 32 * n);
     if (resident == 2) ZK_HIP(hipStreamWaitEvent(c->s_main, c->ev_staged, 0));
     ZK_HIP(hipEventRecord(c->ev_start, c->s_main));
@@ -847,24 +856,35 @@ static int upload_witness(zk_ctx *c, const uint64_t *witness, int canonical, int
 static void store_xyzz(uint64_t *dst, const G1::XYZZ &p) { memcpy(dst, &p, sizeof(p)); }
 static void store_xyzz(uint64_t *dst, const G2::XYZZ &p) { memcpy(dst, &p, sizeof(p)); }
 
-static int prove_enqueue(zk_ctx *c, const uint64_t *witness, int canonical, int resident, const fe *d_h);
-static int prove_submit_impl(zk_ctx *c, const uint64_t *witness, int canonical, int resident = 0, uint32_t k = 1, const fe *d_h = nullptr) {
-    if (!c || !witness) return fail(ZK_ERR_ARG, "null argument");
-    if (c->in_flight) return fail(ZK_ERR_ARG, "a proof is already in flight on this context (collect it first)");
+// phase: PHASE_ALL = the whole proof; PHASE_WITNESS = everything that needs only the witness (upload, witness sorts, A-, B-, L-query);
+// PHASE_H = the H-query of a proof whose witness part is already queued (its coefficients come from d_h)
+enum { PHASE_ALL = 0, PHASE_WITNESS = 1, PHASE_H = 2 };
+static int prove_enqueue(zk_ctx *c, const uint64_t *witness, int canonical, int resident, const fe *d_h, int phase);
+static void drain(zk_ctx *c) {
+    hipStreamSynchronize(c->s_main); hipStreamSynchronize(c->s_acc); hipStreamSynchronize(c->s_a); hipStreamSynchronize(c->s_b); hipStreamSynchronize(c->s_l); hipStreamSynchronize(c->s_h);
+}
+static int prove_submit_impl(zk_ctx *c, const uint64_t *witness, int canonical, int resident = 0, uint32_t k = 1, const fe *d_h = nullptr, int phase = PHASE_ALL) {
+    if (!c || (!witness && phase != PHASE_H)) return fail(ZK_ERR_ARG, "null argument");
+    if (phase == PHASE_H) {
+        if (!c->in_flight || !c->awaiting_h) return fail(ZK_ERR_ARG, "zk_prove_submit_h: no proof is waiting for its H part on this context (zk_prove_submit_defer_h first)");
+        if (!d_h) return fail(ZK_ERR_ARG, "null argument");
+    } else if (c->in_flight) return fail(ZK_ERR_ARG, "a proof is already in flight on this context (collect it first)");
     if (!k || k > c->max_batch) return fail(ZK_ERR_ARG, "batch size exceeds zk_config.max_batch of this context");
     ZK_TRY(use_device(c->device));
-    c->cur_batch = k;
-    const int rc = prove_enqueue(c, witness, canonical, resident, d_h);
+    if (phase != PHASE_H) c->cur_batch = k;
+    const int rc = prove_enqueue(c, witness, canonical, resident, d_h, phase);
     if (rc != ZK_OK) {      // part of the proof may be queued: drain it so that the next submit cannot overwrite buffers still in use
-        hipStreamSynchronize(c->s_main); hipStreamSynchronize(c->s_acc); hipStreamSynchronize(c->s_a); hipStreamSynchronize(c->s_b); hipStreamSynchronize(c->s_l); hipStreamSynchronize(c->s_h);
+        drain(c);
+        c->in_flight = c->awaiting_h = false;
         return rc;
     }
     c->in_flight = true;
+    c->awaiting_h = phase == PHASE_WITNESS;
     return ZK_OK;
 }
 // d_h != nullptr: the H polynomial was computed elsewhere (option 2); this shard's coefficients [rH.lo, rH.hi) lie at d_h
-static int prove_enqueue(zk_ctx *c, const uint64_t *witness, int canonical, int resident, const fe *d_h) {
-    ZK_TRY(upload_witness(c, witness, canonical, resident));
+static int prove_enqueue(zk_ctx *c, const uint64_t *witness, int canonical, int resident, const fe *d_h, int phase) {
+    if (phase != PHASE_H) ZK_TRY(upload_witness(c, witness, canonical, resident));
     // sorts and the H pipeline on m (high priority), accumulations on q (low priority), tails on side streams; longest tail
     // (G2) first.  A sort that finishes on m releases its accumulation on q through ev_sort.
     hipStream_t m = c->s_main, q = c->s_acc;
@@ -888,7 +908,7 @@ static int prove_enqueue(zk_ctx *c, const uint64_t *witness, int canonical, int 
     //    1 083 -> 1 303 proofs/s with three contexts (the A-tail stream: no gain there; 2^16 and larger, and batches: -2 ... -7 %).
     const uint64_t entries = (uint64_t)c->mH.sh.max_entries() * k;
     // tuning aids (cached at context creation): ZK_H_STREAM=0 / 1 forces it, ZK_H_BORROW=a / l / b picks the stream
-    const bool want_split = !c->serial && (c->env_h_stream >= 0 ? c->env_h_stream == 1 : entries < (3ull << 18));
+    const bool want_split = phase == PHASE_ALL && !c->serial && (c->env_h_stream >= 0 ? c->env_h_stream == 1 : entries < (3ull << 18));   // (a proof submitted in two phases keeps the H part on s_main)
     if (want_split && !c->h_stream_made) {
         ZK_HIP(hipEventCreateWithFlags(&c->ev_up, hipEventDisableTiming));
         ZK_HIP(hipEventCreateWithFlags(&c->ev_sort_h, hipEventDisableTiming));
@@ -909,6 +929,7 @@ static int prove_enqueue(zk_ctx *c, const uint64_t *witness, int canonical, int 
         if (split_h) ZK_HIP(hipEventRecord(c->ev_sort_h, hs));
         return ZK_OK;
     };
+    if (phase != PHASE_H) {
     if (split_h) { ZK_HIP(hipEventRecord(c->ev_up, m)); ZK_HIP(hipStreamWaitEvent(hs, c->ev_up, 0)); }
     if (t->share_A || t->share_B || t->share_L) {               // one sort of the witness digits of the window
         ZK_TRY(c->mW.enqueue_sort(c->d_w + t->win_lo, nullptr, t->win_n, 0, m, k, ws));
@@ -927,6 +948,8 @@ static int prove_enqueue(zk_ctx *c, const uint64_t *witness, int canonical, int 
     ZK_HIP(hipEventRecord(c->ev_l0, q));
     ZK_TRY(c->mL.enqueue_reduce(t->share_L ? c->mW.view_for(t->offL) : c->mL.view(), q, c->s_l, tail_lanes));            // tcc:522-530
     ZK_HIP(hipEventRecord(c->ev_l1, c->s_l));
+    }
+    if (phase == PHASE_WITNESS) return ZK_OK;                   // the H-query follows with zk_prove_submit_h
     if (!split_h) { ZK_TRY(h_pipeline()); ZK_TRY(release()); }
     else ZK_HIP(hipStreamWaitEvent(q, c->ev_sort_h, 0));
     ZK_TRY(c->mH.enqueue_reduce(c->mH.view(), q, hs, tail_lanes));
@@ -937,6 +960,7 @@ static int prove_enqueue(zk_ctx *c, const uint64_t *witness, int canonical, int 
 static int prove_collect_impl(zk_ctx *c, zk_partials *out, zk_timings *tm) {     // out == nullptr: the caller takes the device copy
     if (!c) return fail(ZK_ERR_ARG, "null argument");
     if (!c->in_flight) return fail(ZK_ERR_ARG, "no proof in flight on this context");
+    if (c->awaiting_h) return fail(ZK_ERR_ARG, "the proof in flight has no H part yet (zk_prove_submit_h, or zk_prove_abort to drop it)");
     ZK_TRY(use_device(c->device));
     c->in_flight = false;
     ZK_HIP(hipStreamSynchronize(c->s_acc)); ZK_HIP(hipStreamSynchronize(c->s_a)); ZK_HIP(hipStreamSynchronize(c->s_b));
@@ -980,9 +1004,25 @@ static int prove_partial_impl(zk_ctx *c, const uint64_t *witness, int canonical,
 // asynchronous form: enqueue a proof and return; collect later (lets two contexts keep the GPU full)
 extern "C" int zk_prove_submit(zk_ctx *ctx, const uint64_t *witness, int canonical) { return prove_submit_impl(ctx, witness, canonical); }
 extern "C" int zk_prove_submit_resident(zk_ctx *ctx, const void *d_witness, int canonical) { return prove_submit_impl(ctx, (const uint64_t *)d_witness, canonical, 1); }
+// the witness lies in PINNED host memory ("witness already in pinned host memory"): the asynchronous H2D copy reads
+// the caller's buffer itself -- no copy into the context's staging buffer --, so the buffer stays untouched until the proof is collected
+extern "C" int zk_prove_submit_pinned(zk_ctx *ctx, const uint64_t *witness, int canonical) { return prove_submit_impl(ctx, witness, canonical, 3); }
+extern "C" int zk_prove_batch_submit_pinned(zk_ctx *ctx, const uint64_t *witnesses, uint32_t k, int canonical) { return prove_submit_impl(ctx, witnesses, canonical, 3, k); }
+extern "C" int zk_host_alloc(size_t bytes, void **out) {
+    if (!out) return fail(ZK_ERR_ARG, "null argument");
+    ZK_HIP(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    return ZK_OK;
+}
+extern "C" int zk_host_free(void *p) { if (p) ZK_HIP(hipHostFree(p)); return ZK_OK; }
+extern "C" int zk_host_register(void *p, size_t bytes) {
+    if (!p || !bytes) return fail(ZK_ERR_ARG, "null argument");
+    ZK_HIP(hipHostRegister(p, bytes, hipHostRegisterDefault));
+    return ZK_OK;
+}
+extern "C" int zk_host_unregister(void *p) { if (p) ZK_HIP(hipHostUnregister(p)); return ZK_OK; }
 // ---- double-buffered upload: the NEXT witness (k of them, contiguous) goes to the device on a copy stream while a
 // proof may still be in flight on this context; zk_prove_submit_staged then starts it with no upload on its critical path
-extern "C" int zk_prove_stage(zk_ctx *c, const uint64_t *witnesses, uint32_t k, int canonical) {
+static int prove_stage_impl(zk_ctx *c, const uint64_t *witnesses, uint32_t k, int canonical, bool pinned) {
     if (!c || !witnesses) return fail(ZK_ERR_ARG, "null argument");
     if (!k || k > c->max_batch) return fail(ZK_ERR_ARG, "batch size exceeds zk_config.max_batch of this context");
     if (c->staged_k) return fail(ZK_ERR_ARG, "a witness is already staged on this context (submit it first)");
@@ -997,13 +1037,18 @@ extern "C" int zk_prove_stage(zk_ctx *c, const uint64_t *witnesses, uint32_t k, 
         ZK_TRY(stream_take(&c->s_copy, c->device, ROLE_COPY, c->stream_prio[ROLE_COPY]));
         ZK_HIP(hipEventCreateWithFlags(&c->ev_staged, hipEventDisableTiming));
     }
-    ZK_HIP(hipStreamSynchronize(c->s_copy));                    // (the previous staged copy out of h_w2 has long finished; cheap)
-    memcpy(c->h_w2, witnesses, n);
-    ZK_HIP(hipMemcpyAsync(c->d_w2, c->h_w2, n, hipMemcpyHostToDevice, c->s_copy));
+    if (!pinned) {
+        ZK_HIP(hipStreamSynchronize(c->s_copy));                // (the previous staged copy out of h_w2 has long finished; cheap)
+        memcpy(c->h_w2, witnesses, n);
+    }
+    ZK_HIP(hipMemcpyAsync(c->d_w2, pinned ? (const void *)witnesses : (const void *)c->h_w2, n, hipMemcpyHostToDevice, c->s_copy));
     ZK_HIP(hipEventRecord(c->ev_staged, c->s_copy));
     c->staged_k = k; c->staged_canonical = canonical;
     return ZK_OK;
 }
+extern "C" int zk_prove_stage(zk_ctx *c, const uint64_t *witnesses, uint32_t k, int canonical) { return prove_stage_impl(c, witnesses, k, canonical, false); }
+// the same from PINNED host memory: the copy stream reads the caller's buffer where it lies (untouched until that proof is collected)
+extern "C" int zk_prove_stage_pinned(zk_ctx *c, const uint64_t *witnesses, uint32_t k, int canonical) { return prove_stage_impl(c, witnesses, k, canonical, true); }
 extern "C" int zk_prove_submit_staged(zk_ctx *c) {
     if (!c) return fail(ZK_ERR_ARG, "null argument");
     if (!c->staged_k) return fail(ZK_ERR_ARG, "no staged witness on this context (zk_prove_stage first)");
@@ -1017,9 +1062,14 @@ extern "C" int zk_prove_submit_staged(zk_ctx *c) {
 }
 // ---- SURVEY 8(e) option 2: the transform chains of the witness map on different ranks (ethsnarks_amd/sharded.py drives it)
 extern "C" int zk_chain_submit(zk_ctx *c, const uint64_t *witness, int canonical, int which) {
-    if (!c || !witness || which < 0 || which > 2) return fail(ZK_ERR_ARG, "bad argument");
-    if (c->in_flight) return fail(ZK_ERR_ARG, "a proof is in flight on this context (collect it first)");
+    if (!c || which < 0 || which > 2) return fail(ZK_ERR_ARG, "bad argument");
     ZK_TRY(use_device(c->device));
+    if (c->in_flight && c->awaiting_h) {                        // the witness of the deferred proof is already on the device (same stream: ordered)
+        if (c->cur_batch != 1) return fail(ZK_ERR_ARG, "zk_chain_submit: the deferred proof is a batch");
+        return enqueue_chain(c, which);
+    }
+    if (!witness) return fail(ZK_ERR_ARG, "null argument");
+    if (c->in_flight) return fail(ZK_ERR_ARG, "a proof is in flight on this context (collect it first)");
     c->cur_batch = 1;
     ZK_TRY(upload_witness(c, witness, canonical));
     return enqueue_chain(c, which);
@@ -1027,7 +1077,7 @@ extern "C" int zk_chain_submit(zk_ctx *c, const uint64_t *witness, int canonical
 extern "C" const void *zk_chain_device(const zk_ctx *c, int which) { return (c && which >= 0 && which <= 2) ? c->d_a + (size_t)which * c->m : nullptr; }
 extern "C" int zk_h_from_chains_submit(zk_ctx *c, const void *dA, const void *dB, const void *dC) {
     if (!c || !dA || !dB || !dC) return fail(ZK_ERR_ARG, "null argument");
-    if (c->in_flight) return fail(ZK_ERR_ARG, "a proof is in flight on this context (collect it first)");
+    if (c->in_flight && !c->awaiting_h) return fail(ZK_ERR_ARG, "a proof is in flight on this context (collect it first)");
     ZK_TRY(use_device(c->device));
     return enqueue_h_from_chains(c, (const fe *)dA, (const fe *)dB, (const fe *)dC);
 }
@@ -1043,6 +1093,19 @@ extern "C" int zk_chain_wait(zk_ctx *c, int check_degree) {
 extern "C" int zk_prove_submit_with_h(zk_ctx *c, const uint64_t *witness, int canonical, const void *d_h) {
     if (!d_h) return fail(ZK_ERR_ARG, "null argument");
     return prove_submit_impl(c, witness, canonical, 0, 1, (const fe *)d_h);
+}
+// the same proof in two steps, so that the ranks of option 2 start their witness sorts and A-, B-, L-query accumulations BEFORE H
+// exists: zk_prove_submit_defer_h queues everything that needs only the witness; zk_chain_submit / zk_h_from_chains_submit may follow
+// on this context (witness = NULL: the deferred proof's witness is used); zk_prove_submit_h queues the H-query; collect as usual.
+// zk_prove_abort drops a proof that will not get its H part (another rank found the witness unsatisfying): drains, frees the context.
+extern "C" int zk_prove_submit_defer_h(zk_ctx *c, const uint64_t *witness, int canonical) { return prove_submit_impl(c, witness, canonical, 0, 1, nullptr, PHASE_WITNESS); }
+extern "C" int zk_prove_submit_h(zk_ctx *c, const void *d_h) { return prove_submit_impl(c, nullptr, 0, 0, 1, (const fe *)d_h, PHASE_H); }
+extern "C" int zk_prove_abort(zk_ctx *c) {
+    if (!c) return fail(ZK_ERR_ARG, "null argument");
+    ZK_TRY(use_device(c->device));
+    drain(c);
+    c->in_flight = c->awaiting_h = false;
+    return ZK_OK;
 }
 
 // ---- several proofs of the circuit through ONE launch sequence: k witnesses, contiguous, k <= zk_config.max_batch

@@ -64,8 +64,9 @@ EXPORTS = [
     "zk_prove", "zk_prove_timed", "zk_prove_partial", "zk_prove_partial_timed", "zk_prove_combine", "zk_prove_submit", "zk_prove_collect", "zk_proof_to_json",
     "zk_prove_batch", "zk_prove_batch_submit", "zk_prove_batch_submit_resident", "zk_prove_batch_collect",
     "zk_wplan_create", "zk_wplan_solve", "zk_wplan_free", "zk_dev_alloc", "zk_dev_free", "zk_dev_upload", "zk_dev_download",
-    "zk_chain_submit", "zk_chain_device", "zk_h_from_chains_submit", "zk_h_device", "zk_chain_wait", "zk_prove_submit_with_h",
-    "zk_prove_submit_resident", "zk_prove_stage", "zk_prove_submit_staged", "zk_ctx_info", "zk_ctx_partials_device", "zk_prove_collect_device", "zk_prove_combine_device", "zk_launch_count", "zk_profile_begin", "zk_profile_end", "zk_device_info",
+    "zk_chain_submit", "zk_chain_device", "zk_h_from_chains_submit", "zk_h_device", "zk_chain_wait", "zk_prove_submit_with_h", "zk_prove_submit_defer_h", "zk_prove_submit_h", "zk_prove_abort",
+    "zk_prove_submit_pinned", "zk_prove_batch_submit_pinned", "zk_host_alloc", "zk_host_free", "zk_host_register", "zk_host_unregister",
+    "zk_prove_submit_resident", "zk_prove_stage", "zk_prove_stage_pinned", "zk_prove_submit_staged", "zk_ctx_info", "zk_ctx_partials_device", "zk_prove_collect_device", "zk_prove_combine_device", "zk_launch_count", "zk_profile_begin", "zk_profile_end", "zk_device_info", "zk_device_pci_bus_id",
     "zk_verify",
     "zk_ntt", "zk_witness_map", "zk_msm_g1", "zk_msm_g2", "zk_field_mul", "zk_fr_convert",
 ]
@@ -386,6 +387,22 @@ class ProverContext:
         (V + 1) x 32 bytes); the caller keeps that buffer untouched until collect()"""
         _check(_lib.zk_prove_submit_resident(self._h, C.c_void_p(device_ptr), int(canonical)))
 
+    def submit_pinned(self, pinned, canonical=False, k=1):
+        """zk_prove_submit_pinned / zk_prove_batch_submit_pinned: `pinned` is a PinnedBuffer (or a pinned numpy view) holding k
+        witnesses; the H2D copy reads it in place, so it must stay untouched until the proof is collected"""
+        lib = load_library(_lib_path_loaded)
+        ptr = C.c_void_p(pinned.ptr if isinstance(pinned, PinnedBuffer) else pinned.ctypes.data)
+        if k == 1:
+            _check(lib.zk_prove_submit_pinned(self._h, ptr, int(canonical)))
+        else:
+            _check(lib.zk_prove_batch_submit_pinned(self._h, ptr, C.c_uint32(k), int(canonical)))
+        return k
+
+    def stage_pinned(self, pinned, canonical=False, k=1):
+        """zk_prove_stage_pinned: the NEXT proof's k witnesses go to the device from a PinnedBuffer, in place, on the copy stream"""
+        ptr = C.c_void_p(pinned.ptr if isinstance(pinned, PinnedBuffer) else pinned.ctypes.data)
+        _check(load_library(_lib_path_loaded).zk_prove_stage_pinned(self._h, ptr, C.c_uint32(k), int(canonical)))
+
     def stage(self, witnesses, canonical=False):
         """zk_prove_stage: copy the NEXT witness (or k of them, shape (k, V + 1, 4)) to the device while a proof may still be
         in flight on this context; returns k"""
@@ -415,7 +432,17 @@ class ProverContext:
 
     # SURVEY 8(e) option 2 building blocks (ethsnarks_amd/sharded.py drives them)
     def chain_submit(self, witness, which, canonical=False):
-        _check(_lib.zk_chain_submit(self._h, _p64(self._w(witness)), int(canonical), int(which)))
+        """witness None: the chain of the proof submitted with submit_defer_h (its witness is already on the device)"""
+        _check(_lib.zk_chain_submit(self._h, _p64(self._w(witness)) if witness is not None else None, int(canonical), int(which)))
+
+    def submit_defer_h(self, witness, canonical=False):
+        _check(_lib.zk_prove_submit_defer_h(self._h, _p64(self._w(witness)), int(canonical)))
+
+    def submit_h(self, h_device_ptr):
+        _check(_lib.zk_prove_submit_h(self._h, C.c_void_p(h_device_ptr)))
+
+    def abort(self):
+        _check(_lib.zk_prove_abort(self._h))
 
     def chain_device_ptr(self, which):
         return int(_lib.zk_chain_device(self._h, int(which)))
@@ -529,6 +556,29 @@ def stub_test_proof_verify(r1cs, witness, **kw):
 
 
 # ---- witness completion on the GPU
+class PinnedBuffer:
+    """zk_host_alloc: pinned host memory the H2D copy of zk_prove_submit_pinned reads in place; `array` is a numpy uint64 view"""
+
+    def __init__(self, nbytes):
+        lib = load_library(_lib_path_loaded)
+        p = C.c_void_p()
+        _check(lib.zk_host_alloc(C.c_size_t(nbytes), C.byref(p)))
+        self.ptr, self.nbytes = p.value, nbytes
+        self.array = np.frombuffer((C.c_uint8 * nbytes).from_address(self.ptr), dtype=np.uint64)
+
+    def free(self):
+        if self.ptr:
+            self.array = None
+            load_library(_lib_path_loaded).zk_host_free(C.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class DeviceBuffer:
     """device memory through the library (zk_dev_*): for hosts without a HIP binding of their own"""
 
@@ -620,6 +670,12 @@ def device_info(device=0):
 
 
 # ---- kernel-level entry points
+def device_pci_bus_id(device=0):
+    buf = C.create_string_buffer(64)
+    _check(load_library(_lib_path_loaded).zk_device_pci_bus_id(int(device), buf, C.c_size_t(len(buf))))
+    return buf.value.decode()
+
+
 def ntt(data, logm, inverse=False, coset=False, device=0):
     a = _c64(data).copy()
     _check(load_library(_lib_path_loaded).zk_ntt(_p64(a), C.c_uint32(logm), int(inverse), int(coset), device))

@@ -57,40 +57,60 @@ class ShardedProver:
         """SURVEY 8(e) option 2: instead of every rank recomputing the whole witness map, ranks 0, 1, 2 run the A, B and C
         transform chains (row evaluations, iFFT, cosetFFT), ranks 1 and 2 send their m coset evaluations to rank 0 (two
         32 m-byte peer transfers), rank 0 forms H ((a b - c) / Z, icosetFFT: 3 transforms on the critical path instead of 7)
-        and sends every rank the coefficients its H-query shard multiplies.  Needs at least three ranks."""
+        and sends every rank the coefficients its H-query shard multiplies.  Needs at least three ranks.
+
+        Pipelined: every rank first queues what needs only the witness (zk_prove_submit_defer_h: upload, witness sort, A-, B-,
+        L-query accumulations), so its GPU works on three of the four multi-exponentiations while the chains travel; the H-query
+        is queued when the coefficients arrive (zk_prove_submit_h).  An unsatisfying witness is found by rank 0 alone (degree of
+        H): it broadcasts a status word before the scatter, and EVERY rank drops its deferred proof and raises ZK_ERR_DEGREE
+        together instead of waiting for coefficients that never come."""
+        from .prover import ZkError
         ctx, dist, rank, world = self.ctx, self.dist, self.dist.get_rank(), self.world
         if world < 3:
             return self.prove_struct(witness, canonical)
         m = ctx.r1cs.domain_size
         shard = lambda r: ((m - 1) * r // world, (m - 1) * (r + 1) // world)      # zk_ctx_create's base-range rule for H
-        if rank < 3:
-            ctx.chain_submit(witness, rank, canonical)
-            ctx.chain_wait()
-        if rank == 0:
-            got = [torch.empty(32 * m, dtype=torch.uint8, device=self.device) for _ in range(2)]
-            reqs = [dist.irecv(got[i], src=i + 1) for i in range(2)]
-            for q in reqs:
-                q.wait()
-            if self.device.type == "cuda":
-                torch.cuda.current_stream(self.device).synchronize()
-            ctx.h_from_chains_submit(ctx.chain_device_ptr(0), got[0].data_ptr(), got[1].data_ptr())
-            ctx.chain_wait(check_degree=True)
-            h = self._view(ctx.h_device_ptr(), 32 * m)
-            reqs = [dist.isend(h[32 * shard(r)[0]:32 * shard(r)[1]], dst=r) for r in range(1, world)]
-            lo, hi = shard(0)
-            ctx.submit_with_h(witness, ctx.h_device_ptr() + 32 * lo, canonical)
-            for q in reqs:
-                q.wait()
-        else:
+        sync = (lambda: torch.cuda.current_stream(self.device).synchronize()) if self.device.type == "cuda" else (lambda: None)
+        status = torch.zeros(1, dtype=torch.int32, device=self.device)
+        ctx.submit_defer_h(witness, canonical)
+        try:
             if rank < 3:
+                ctx.chain_submit(None, rank)                            # behind the witness sorts on the main stream, beside the accumulations
+            if rank == 0:
+                got = [torch.empty(32 * m, dtype=torch.uint8, device=self.device) for _ in range(2)]
+                reqs = [dist.irecv(got[i], src=i + 1) for i in range(2)]
+                ctx.chain_wait()
+                for q in reqs:
+                    q.wait()
+                sync()
+                ctx.h_from_chains_submit(ctx.chain_device_ptr(0), got[0].data_ptr(), got[1].data_ptr())
+                try:
+                    ctx.chain_wait(check_degree=True)
+                except ZkError as e:
+                    status[0] = e.code
+            elif rank < 3:
+                ctx.chain_wait()
                 dist.send(self._view(ctx.chain_device_ptr(rank), 32 * m), dst=0)
-            lo, hi = shard(rank)
-            mine_h = torch.empty(32 * (hi - lo), dtype=torch.uint8, device=self.device)
-            dist.recv(mine_h, src=0)
-            if self.device.type == "cuda":
-                torch.cuda.current_stream(self.device).synchronize()
-            self._keep_h = mine_h                                       # stays alive until the proof is collected
-            ctx.submit_with_h(witness, mine_h.data_ptr(), canonical)
+            dist.broadcast(status, src=0)                               # every rank learns whether H exists before it waits for its share
+            code = int(status.item())
+            if code:
+                raise ZkError(code, "h[m-1] != 0 on rank 0: the witness does not satisfy the constraint system")
+            if rank == 0:
+                h = self._view(ctx.h_device_ptr(), 32 * m)
+                reqs = [dist.isend(h[32 * shard(r)[0]:32 * shard(r)[1]], dst=r) for r in range(1, world)]
+                ctx.submit_h(ctx.h_device_ptr() + 32 * shard(0)[0])
+                for q in reqs:
+                    q.wait()
+            else:
+                lo, hi = shard(rank)
+                mine_h = torch.empty(32 * (hi - lo), dtype=torch.uint8, device=self.device)
+                dist.recv(mine_h, src=0)
+                sync()
+                self._keep_h = mine_h                                   # stays alive until the proof is collected
+                ctx.submit_h(mine_h.data_ptr())
+        except Exception:
+            ctx.abort()                                                 # the deferred proof will not be completed: drain, free the context
+            raise
         proof, _ = self.finish()
         return proof
 

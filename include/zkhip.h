@@ -211,13 +211,34 @@ int zk_h_from_chains_submit(zk_ctx *ctx, const void *dA, const void *dB, const v
 const void *zk_h_device(const zk_ctx *ctx);
 int zk_chain_wait(zk_ctx *ctx, int check_degree);
 int zk_prove_submit_with_h(zk_ctx *ctx, const uint64_t *witness, int canonical, const void *d_h);
+/* zk_prove_submit_with_h in two steps, so that every rank starts its witness sorts and A-, B-, L-query accumulations BEFORE H exists:
+ *   zk_prove_submit_defer_h  queues everything that needs only the witness (upload, witness sorts, A-, B-, L-query);
+ *                            zk_chain_submit (witness = NULL: the deferred proof's) / zk_h_from_chains_submit may follow on this context
+ *   zk_prove_submit_h        queues the H-query from this shard's coefficients; collect as usual
+ *   zk_prove_abort           drops a proof in flight (e.g. one that will not get its H part because rank 0 found the witness
+ *                            unsatisfying): drains the context's streams, nothing is returned */
+int zk_prove_submit_defer_h(zk_ctx *ctx, const uint64_t *witness, int canonical);
+int zk_prove_submit_h(zk_ctx *ctx, const void *d_h);
+int zk_prove_abort(zk_ctx *ctx);
 /* zk_prove_submit for a witness that is already resident in the context's device memory (d_witness = device
  * pointer to (V + 1) x 32 bytes, e.g. written by a GPU witness generator); it must stay untouched until collected */
 int zk_prove_submit_resident(zk_ctx *ctx, const void *d_witness, int canonical);
+/* zk_prove_submit for a witness in PINNED host memory (SURVEY 8(d)'s metric: "witness already in pinned host memory"): the
+ * asynchronous H2D copy reads the caller's buffer where it lies -- zk_prove_submit copies a pageable buffer into the context's
+ * pinned staging buffer first, 33 MB of memcpy per proof at 2^20 --, so it must stay untouched until the proof is collected.
+ * zk_host_alloc / zk_host_free: pinned host memory; zk_host_register / _unregister: pin a buffer the caller already owns
+ * (pb.values of a protoboard that is proven repeatedly). */
+int zk_prove_submit_pinned(zk_ctx *ctx, const uint64_t *witness, int canonical);
+int zk_prove_batch_submit_pinned(zk_ctx *ctx, const uint64_t *witnesses, uint32_t k, int canonical);
+int zk_host_alloc(size_t bytes, void **out);
+int zk_host_free(void *p);
+int zk_host_register(void *p, size_t bytes);
+int zk_host_unregister(void *p);
 /* double-buffered upload: zk_prove_stage copies the NEXT witness (k of them, k <= zk_config.max_batch) to the
  * device on a copy stream, also while a proof is in flight on this context; zk_prove_submit_staged starts that proof with no
  * upload on its critical path (collect as usual: zk_prove_collect / zk_prove_batch_collect).  One staged witness per context. */
 int zk_prove_stage(zk_ctx *ctx, const uint64_t *witnesses, uint32_t k, int canonical);
+int zk_prove_stage_pinned(zk_ctx *ctx, const uint64_t *witnesses, uint32_t k, int canonical);   /* pinned source: no staging memcpy; untouched until collected */
 int zk_prove_submit_staged(zk_ctx *ctx);
 /* info[3q .. 3q+2] = {window bits c, windows W, buckets 2^(c-1)} of query q = A, B, H, L; info[12..14] = the A-, B-, L-query
  * ride the shared witness sort; info[15] = domain size m */
@@ -258,6 +279,8 @@ uint64_t zk_launch_count(void);
 int zk_profile_begin(void);
 int zk_profile_end(float *kernel_ms_sum, uint32_t *launches, char *buf, size_t cap);
 int zk_device_info(int device, uint32_t *compute_units, uint32_t *clock_mhz, char *name, size_t name_cap);
+/* "domain:bus:device.function" of the HIP device (multi-GPU runs report it per rank: proof that the ranks sit on distinct GPUs) */
+int zk_device_pci_bus_id(int device, char *buf, size_t cap);
 
 /* ---- kernel-level entry points (parity tests / micro-benchmarks); host buffers in and out */
 int zk_ntt(uint64_t *data, uint32_t logm, int inverse, int coset, int device);

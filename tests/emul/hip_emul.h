@@ -156,6 +156,9 @@ template <class T> hipError_t hipMalloc(T **p, size_t n) { *p = (T *)calloc(n ? 
 inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
 template <class T> hipError_t hipHostMalloc(T **p, size_t n, unsigned = 0) { *p = (T *)calloc(n ? n : 1, 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
+enum { hipHostRegisterDefault = 0 };
+inline hipError_t hipHostRegister(void *, size_t, unsigned) { return hipSuccess; }
+inline hipError_t hipHostUnregister(void *) { return hipSuccess; }
 inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { if (n) memmove(d, s, n); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind k, hipStream_t) { return hipMemcpy(d, s, n, k); }
 inline hipError_t hipMemcpy2DAsync(void *d, size_t dpitch, const void *s, size_t spitch, size_t width, size_t height, hipMemcpyKind, hipStream_t) {

@@ -36,7 +36,18 @@ def _worker(rank, world, port, emul_so, q):
     got = P.proof_to_json(sp.prove_struct(wm), wm[1:2])
     got2 = P.proof_to_json(sp.prove_struct(wm, timings=True)[0], wm[1:2])
     got3 = P.proof_to_json(sp.prove_struct_split_witness_map(wm), wm[1:2])      # SURVEY 8(e) option 2 (three ranks or more)
-    q.put((rank, got == expect and got2 == expect and got3 == expect and shared))
+    # an unsatisfying witness through option 2: rank 0 alone forms H, EVERY rank must raise ZK_ERR_DEGREE (no rank is left waiting
+    # for coefficients), and the contexts prove again afterwards
+    bad = wm.copy(); bad[7] = wm[8]
+    all_raise = True
+    if world >= 3:
+        try:
+            sp.prove_struct_split_witness_map(bad)
+            all_raise = False
+        except P.ZkError as e:
+            all_raise = e.code == 7
+        all_raise = all_raise and P.proof_to_json(sp.prove_struct_split_witness_map(wm), wm[1:2]) == expect
+    q.put((rank, got == expect and got2 == expect and got3 == expect and shared and all_raise))
     dist.barrier()
     dist.destroy_process_group()
 

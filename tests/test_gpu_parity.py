@@ -381,6 +381,40 @@ def test_staged_upload_double_buffering(hip, oracle):
     assert hip.prove(c, wa) == ea                                            # ordinary submit after the buffers were swapped
 
 
+def test_pinned_witness_submit_and_stage(hip, oracle):
+    """SURVEY 8(d)'s hand-over: the witness lies in pinned host memory (zk_host_alloc) and is copied from where it lies --
+    zk_prove_submit_pinned on the proof's own stream, zk_prove_stage_pinned ahead of time on the copy stream; a registered
+    caller-owned buffer (zk_host_register) works the same; proofs unchanged"""
+    r, w = R.random_r1cs(900, 2, seed=41)
+    _, w2 = R.random_r1cs(900, 2, seed=41, witness_seed=7)
+    wa, wb = F.fr_to_mont(w), F.fr_to_mont(w2)
+    pk_o, _ = oracle.keygen(r, seed=6)
+    ea, eb = oracle.prove(pk_o, r, wa)[0], oracle.prove(pk_o, r, wb)[0]
+    pk = hip.ProvingKey.from_parts(**pk_o.parts())
+    c = hip.ProverContext(pk, r, max_batch=2)
+    pa, pb = hip.PinnedBuffer(wa.nbytes), hip.PinnedBuffer(2 * wa.nbytes)
+    pa.array[:] = wa.reshape(-1)
+    pb.array[:] = np.stack([wb, wa]).reshape(-1)
+    c.submit_pinned(pa)
+    c.stage_pinned(pb, k=2)                                                  # a batch of two, copied while proof a runs
+    part, _ = c.collect()
+    assert hip.proof_to_json(c.prove_combine(part), wa[1:3]) == ea
+    c.submit_staged()
+    parts, _ = c.collect_batch(2)
+    assert [hip.proof_to_json(c.prove_combine(parts[i:i + 1]), x[1:3]) for i, x in enumerate((wb, wa))] == [eb, ea]
+    c.submit_pinned(pb, k=2)
+    parts, _ = c.collect_batch(2)
+    assert hip.proof_to_json(c.prove_combine(parts[0:1]), wb[1:3]) == eb
+    own = np.ascontiguousarray(wb).copy()                                     # a buffer the caller owns, pinned in place
+    lib = hip.load_library(hip._lib_path_loaded)
+    assert lib.zk_host_register(own.ctypes.data_as(hip.C.c_void_p), hip.C.c_size_t(own.nbytes)) == 0
+    c.submit_pinned(own)
+    part, _ = c.collect()
+    assert hip.proof_to_json(c.prove_combine(part), wb[1:3]) == eb
+    assert lib.zk_host_unregister(own.ctypes.data_as(hip.C.c_void_p)) == 0
+    pa.free(); pb.free(); c.close()
+
+
 def test_async_submit_collect_two_contexts(hip, oracle):
     r, w = R.synthetic_chain((1 << 12) - 2, 1)
     wm = F.fr_to_mont(w)
@@ -478,6 +512,75 @@ def test_config5_size_2pow22_sharded_over_eight(hip, oracle):
     ctx = hip.ProverContext(pk, r, shard_rank=0, shard_count=8)
     assert hip.proof_to_json(ctx.prove_combine(np.stack(shards)), wm[1:2]) == got
     ctx.close()
+
+
+@pytest.mark.parametrize("logm", [12, 18])
+def test_option2_split_witness_map_entry_points_on_one_device(hip, oracle, logm):
+    """SURVEY 8(e) option 2 on real hardware as far as one GPU allows: three same-device contexts own shards 0..2 of 3, context k
+    runs transform chain k (zk_chain_submit: A, B, C), context 0 forms H from the three chain buffers handed over as plain device
+    pointers (zk_h_from_chains_submit), every context proves its shard from h[lo..hi) (zk_prove_submit_with_h); the folded proof
+    equals the oracle's and the closed form; an unsatisfying witness fails the degree check where H is formed."""
+    r, w = R.synthetic_chain((1 << logm) - 2, 1)
+    wm = F.fr_to_mont(w)
+    pk, _ = hip.keygen(r, seed=70 + logm)
+    expect, _ = oracle.prove(oracle.pk_from_parts(pk.parts()), r, wm)
+    assert expect == oracle.proof_from_trapdoor(r, wm, oracle.toxic_from_seed(70 + logm))
+    G, m = 3, r.domain_size
+    ctxs = [hip.ProverContext(pk, r, shard_rank=k, shard_count=G) for k in range(G)]
+
+    def run(wit):
+        for k in range(G):
+            ctxs[k].chain_submit(wit, k)
+        for k in range(G):
+            ctxs[k].chain_wait()
+        ctxs[0].h_from_chains_submit(ctxs[0].chain_device_ptr(0), ctxs[1].chain_device_ptr(1), ctxs[2].chain_device_ptr(2))
+        ctxs[0].chain_wait(check_degree=True)
+        for k in range(G):
+            ctxs[k].submit_with_h(wit, ctxs[0].h_device_ptr() + 32 * ((m - 1) * k // G))
+        parts = [ctxs[k].collect()[0] for k in range(G)]
+        return hip.proof_to_json(ctxs[0].prove_combine(np.stack(parts)), wit[1:2])
+
+    def run_pipelined(wit):
+        """the two-step form the multi-rank driver uses: the witness part of every shard is queued before H exists"""
+        for k in range(G):
+            ctxs[k].submit_defer_h(wit)
+        try:
+            for k in range(G):
+                ctxs[k].chain_submit(None, k)                                # witness = the deferred proof's
+            for k in range(G):
+                ctxs[k].chain_wait()
+            ctxs[0].h_from_chains_submit(ctxs[0].chain_device_ptr(0), ctxs[1].chain_device_ptr(1), ctxs[2].chain_device_ptr(2))
+            ctxs[0].chain_wait(check_degree=True)
+        except hip.ZkError:
+            for k in range(G):
+                ctxs[k].abort()
+            raise
+        with pytest.raises(hip.ZkError):
+            ctxs[1].collect()                                                # no H part yet
+        for k in range(G):
+            ctxs[k].submit_h(ctxs[0].h_device_ptr() + 32 * ((m - 1) * k // G))
+        parts = [ctxs[k].collect()[0] for k in range(G)]
+        return hip.proof_to_json(ctxs[0].prove_combine(np.stack(parts)), wit[1:2])
+
+    assert run(wm) == expect
+    assert run(wm) == expect                                                 # the contexts are reusable
+    assert run_pipelined(wm) == expect
+    with pytest.raises(hip.ZkError):
+        ctxs[0].submit_h(ctxs[0].h_device_ptr())                             # nothing deferred
+    bad = wm.copy(); bad[5] = wm[6]
+    with pytest.raises(hip.ZkError) as e:
+        run(bad)
+    assert e.value.code == 7                                                 # ZK_ERR_DEGREE, raised where H is formed
+    assert run(wm) == expect                                                 # ... and the contexts survive it
+    with pytest.raises(hip.ZkError) as e:
+        run_pipelined(bad)
+    assert e.value.code == 7
+    assert run_pipelined(wm) == expect
+    # the replicated path of the same shards gives the same proof
+    parts = [c.prove_partial(wm) for c in ctxs]
+    assert hip.proof_to_json(ctxs[0].prove_combine(np.stack(parts)), wm[1:2]) == expect
+    for c in ctxs:
+        c.close()
 
 
 def test_stub_test_proof_verify_and_static_triple(hip):
