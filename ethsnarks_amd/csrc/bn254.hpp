@@ -283,6 +283,91 @@ struct Field {
     static __device__ __forceinline__ fe lmul4(const fe &a, const fe &b, const fe &c, const fe &d, const fe &e, const fe &f, const fe &g, const fe &h) {
         const fe *const op[8] = {&a, &b, &c, &d, &e, &f, &g, &h}; return mul_fips_n<4, false>(op);
     }
+    // ---- dual forms: TWO independent products advance together, instruction by instruction, so that the serial tail of every
+    // column of one (last multiply-add -> m_i -> m_i p_0 -> next column's addend) fills with the other's multiply-adds
+    // (fips_asm.hpp, *_x2).  Measured (tools/mulbench.cpp, profiles/r03_dual_issue.txt): a chain of single products gains 14 % at
+    // 2 waves/SIMD, 9 % at 4 (140 G/s = the issue bound); two-term dot products -- what Fq2 is made of -- gain nothing, their
+    // columns are long enough.  Used by the G1 mixed addition (Curve::madd, PAIRS), which pays for the second set of m / t words
+    // with one wave per SIMD (3 instead of 4: ZK_G1_WPS).
+    template <int N, int J0, int I>
+    static __device__ __forceinline__ void col_ab_x2(uint64_t &l0, uint32_t &h0, uint64_t &l1, uint32_t &h1, const fe &a, const fe &b, const fe &c, const fe &d) {
+        if constexpr (N > 4) { col_ab_x2<4, J0, I>(l0, h0, l1, h1, a, b, c, d); col_ab_x2<N - 4, J0 + 4, I>(l0, h0, l1, h1, a, b, c, d); }
+        else {
+#define ZK_AB(k) a.l[J0 + k], b.l[I - J0 - k]
+#define ZK_CD(k) c.l[J0 + k], d.l[I - J0 - k]
+            if constexpr (N == 1) fips::mac1_vv_x2(l0, h0, l1, h1, ZK_AB(0), ZK_CD(0));
+            if constexpr (N == 2) fips::mac2_vv_x2(l0, h0, l1, h1, ZK_AB(0), ZK_AB(1), ZK_CD(0), ZK_CD(1));
+            if constexpr (N == 3) fips::mac3_vv_x2(l0, h0, l1, h1, ZK_AB(0), ZK_AB(1), ZK_AB(2), ZK_CD(0), ZK_CD(1), ZK_CD(2));
+            if constexpr (N == 4) fips::mac4_vv_x2(l0, h0, l1, h1, ZK_AB(0), ZK_AB(1), ZK_AB(2), ZK_AB(3), ZK_CD(0), ZK_CD(1), ZK_CD(2), ZK_CD(3));
+        }
+    }
+    template <int N, int J0, int I>
+    static __device__ __forceinline__ void col_ab_set_x2(uint64_t &l0, uint32_t &h0, uint64_t &l1, uint32_t &h1, uint64_t ad0, uint64_t ad1, const fe &a, const fe &b, const fe &c, const fe &d) {
+        if constexpr (N > 4) { col_ab_set_x2<4, J0, I>(l0, h0, l1, h1, ad0, ad1, a, b, c, d); col_ab_x2<N - 4, J0 + 4, I>(l0, h0, l1, h1, a, b, c, d); }
+        else {
+            if constexpr (N == 1) fips::mac1_vv_set_x2(l0, h0, l1, h1, ad0, ad1, ZK_AB(0), ZK_CD(0));
+            if constexpr (N == 2) fips::mac2_vv_set_x2(l0, h0, l1, h1, ad0, ad1, ZK_AB(0), ZK_AB(1), ZK_CD(0), ZK_CD(1));
+            if constexpr (N == 3) fips::mac3_vv_set_x2(l0, h0, l1, h1, ad0, ad1, ZK_AB(0), ZK_AB(1), ZK_AB(2), ZK_CD(0), ZK_CD(1), ZK_CD(2));
+            if constexpr (N == 4) fips::mac4_vv_set_x2(l0, h0, l1, h1, ad0, ad1, ZK_AB(0), ZK_AB(1), ZK_AB(2), ZK_AB(3), ZK_CD(0), ZK_CD(1), ZK_CD(2), ZK_CD(3));
+#undef ZK_AB
+#undef ZK_CD
+        }
+    }
+    template <int N, int J0, int I>
+    static __device__ __forceinline__ void col_mp_x2(uint64_t &l0, uint32_t &h0, uint64_t &l1, uint32_t &h1, const uint32_t (&m0)[8], const uint32_t (&m1)[8]) {
+        if constexpr (N > 4) { col_mp_x2<4, J0, I>(l0, h0, l1, h1, m0, m1); col_mp_x2<N - 4, J0 + 4, I>(l0, h0, l1, h1, m0, m1); }
+        else {
+#define ZK_P(k) P::p(I - J0 - k)
+            if constexpr (N == 1) fips::mac1_vs_x2(l0, h0, l1, h1, m0[J0], m1[J0], ZK_P(0));
+            if constexpr (N == 2) fips::mac2_vs_x2(l0, h0, l1, h1, m0[J0], m0[J0 + 1], m1[J0], m1[J0 + 1], ZK_P(0), ZK_P(1));
+            if constexpr (N == 3) fips::mac3_vs_x2(l0, h0, l1, h1, m0[J0], m0[J0 + 1], m0[J0 + 2], m1[J0], m1[J0 + 1], m1[J0 + 2], ZK_P(0), ZK_P(1), ZK_P(2));
+            if constexpr (N == 4) fips::mac4_vs_x2(l0, h0, l1, h1, m0[J0], m0[J0 + 1], m0[J0 + 2], m0[J0 + 3], m1[J0], m1[J0 + 1], m1[J0 + 2], m1[J0 + 3], ZK_P(0), ZK_P(1), ZK_P(2), ZK_P(3));
+#undef ZK_P
+        }
+    }
+    // (r0, r1) = (sum of NP products of opA, sum of NP products of opB), each with one Montgomery reduction, bounds as mul_fips_n
+    template <int NP>
+    static __device__ __forceinline__ void mul_fips_n_x2(const fe *const (&A)[2 * NP], const fe *const (&B)[2 * NP], fe &r0, fe &r1) {
+        uint64_t l0, l1, ad0, ad1; uint32_t h0, h1;
+        uint32_t m0[8], m1[8], t0[8], t1[8];
+        fips::mul1_vv_x2(l0, l1, A[0]->l[0], A[1]->l[0], B[0]->l[0], B[1]->l[0]);
+        if constexpr (NP >= 2) fips::mac1_vv_sethi_x2(l0, h0, l1, h1, A[2]->l[0], A[3]->l[0], B[2]->l[0], B[3]->l[0]);
+        if constexpr (NP >= 4) { fips::mac1_vv_x2(l0, h0, l1, h1, A[4]->l[0], A[5]->l[0], B[4]->l[0], B[5]->l[0]); fips::mac1_vv_x2(l0, h0, l1, h1, A[6]->l[0], A[7]->l[0], B[6]->l[0], B[7]->l[0]); }
+        fips::mullo_vs_x2(m0[0], m1[0], (uint32_t)l0, (uint32_t)l1, P::inv);
+        if constexpr (NP == 1) fips::mac1_vs_sethi_x2(l0, h0, l1, h1, m0[0], m1[0], P::p(0)); else fips::mac1_vs_x2(l0, h0, l1, h1, m0[0], m1[0], P::p(0));
+        ad0 = next_addend(l0, h0); ad1 = next_addend(l1, h1);
+#define ZK_LOW(I) \
+        col_ab_set_x2<I + 1, 0, I>(l0, h0, l1, h1, ad0, ad1, *A[0], *A[1], *B[0], *B[1]); \
+        if constexpr (NP >= 2) col_ab_x2<I + 1, 0, I>(l0, h0, l1, h1, *A[2], *A[3], *B[2], *B[3]); \
+        if constexpr (NP >= 4) { col_ab_x2<I + 1, 0, I>(l0, h0, l1, h1, *A[4], *A[5], *B[4], *B[5]); col_ab_x2<I + 1, 0, I>(l0, h0, l1, h1, *A[6], *A[7], *B[6], *B[7]); } \
+        col_mp_x2<I, 0, I>(l0, h0, l1, h1, m0, m1); \
+        fips::mullo_vs_x2(m0[I], m1[I], (uint32_t)l0, (uint32_t)l1, P::inv); \
+        fips::mac1_vs_x2(l0, h0, l1, h1, m0[I], m1[I], P::p(0)); \
+        ad0 = next_addend(l0, h0); ad1 = next_addend(l1, h1);
+#define ZK_HIGH(I) \
+        col_ab_set_x2<15 - I, I - 7, I>(l0, h0, l1, h1, ad0, ad1, *A[0], *A[1], *B[0], *B[1]); \
+        if constexpr (NP >= 2) col_ab_x2<15 - I, I - 7, I>(l0, h0, l1, h1, *A[2], *A[3], *B[2], *B[3]); \
+        if constexpr (NP >= 4) { col_ab_x2<15 - I, I - 7, I>(l0, h0, l1, h1, *A[4], *A[5], *B[4], *B[5]); col_ab_x2<15 - I, I - 7, I>(l0, h0, l1, h1, *A[6], *A[7], *B[6], *B[7]); } \
+        col_mp_x2<15 - I, I - 7, I>(l0, h0, l1, h1, m0, m1); \
+        t0[I - 8] = (uint32_t)l0; t1[I - 8] = (uint32_t)l1; \
+        ad0 = next_addend(l0, h0); ad1 = next_addend(l1, h1);
+        ZK_LOW(1) ZK_LOW(2) ZK_LOW(3) ZK_LOW(4) ZK_LOW(5) ZK_LOW(6) ZK_LOW(7)
+        ZK_HIGH(8) ZK_HIGH(9) ZK_HIGH(10) ZK_HIGH(11) ZK_HIGH(12) ZK_HIGH(13) ZK_HIGH(14)
+#undef ZK_LOW
+#undef ZK_HIGH
+        t0[7] = (uint32_t)ad0; t1[7] = (uint32_t)ad1;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { r0.l[i] = t0[i]; r1.l[i] = t1[i]; }
+        if constexpr (NP >= 2) { if constexpr (P::is_fq) { fips::reduce8_fq2(r0.l); fips::reduce8_fq2(r1.l); } else { fips::reduce8_fr2(r0.l); fips::reduce8_fr2(r1.l); } }
+        if constexpr (NP >= 4) { if constexpr (P::is_fq) { fips::reduce8_fq2(r0.l); fips::reduce8_fq2(r1.l); } else { fips::reduce8_fr2(r0.l); fips::reduce8_fr2(r1.l); } }
+    }
+    // loose-domain pairs: (a b, c d); (a b + c d, e f + g h); and the four-term form
+    static __device__ __forceinline__ void lmul_x2(const fe &a, const fe &b, const fe &c, const fe &d, fe &r0, fe &r1) {
+        const fe *const A[2] = {&a, &b}; const fe *const B[2] = {&c, &d}; mul_fips_n_x2<1>(A, B, r0, r1);
+    }
+    static __device__ __forceinline__ void lmul2_x2(const fe &a, const fe &b, const fe &c, const fe &d, const fe &e, const fe &f, const fe &g, const fe &h, fe &r0, fe &r1) {
+        const fe *const A[4] = {&a, &b, &c, &d}; const fe *const B[4] = {&e, &f, &g, &h}; mul_fips_n_x2<2>(A, B, r0, r1);   // (tools/mulbench.cpp measures it)
+    }
 #else
     static ZK_HD fe mul(const fe &a, const fe &b) { return mul_cios(a, b); }
 #endif
@@ -321,6 +406,17 @@ struct Field {
     static ZK_HD fe lsub(const fe &a, const fe &b) { return sub(a, b); }
     static ZK_HD bool lis_zero(const fe &a) { return is_zero(a); }
 #endif
+#if !(defined(__HIP_DEVICE_COMPILE__) && !defined(ZK_NO_ASM))
+    static ZK_HD void lmul_x2(const fe &a, const fe &b, const fe &c, const fe &d, fe &r0, fe &r1) { r0 = lmul(a, b); r1 = lmul(c, d); }
+#endif
+    // two independent products of the G1 formulas as one call (dual issue on the device; PAIRS: whether the formulas use it)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZK_NO_ASM) && !defined(ZK_NO_X2) && !defined(ZK_G1_NO_X2)
+    static constexpr bool PAIRS = true;
+#else
+    static constexpr bool PAIRS = false;
+#endif
+    static ZK_HD void lmul_pair(const fe &a, const fe &b, const fe &c, const fe &d, fe &r0, fe &r1) { lmul_x2(a, b, c, d, r0, r1); }
+    static ZK_HD void lsqr_pair(const fe &a, const fe &b, fe &r0, fe &r1) { lmul_pair(a, a, b, b, r0, r1); }
     static ZK_HD fe lsqr(const fe &a) { return lmul(a, a); }
     static ZK_HD fe ldbl(const fe &a) { return ladd(a, a); }
     static ZK_HD fe lneg(const fe &a) { return lsub(zero(), a); }
@@ -421,10 +517,15 @@ struct Fq2 {
     // Karatsuba's 3 x 136 multiplies plus five modular additions -- fewer VALU issue slots on gfx950
     static ZK_HD fe2 lmul(const fe2 &a, const fe2 &b) {
         fe2 r;
+        // (c0 and c1 as a dual-issue pair, Field::lmul2_x2, was measured: no gain -- a two-term dot product at 2 waves/SIMD already
+        // runs at 91 % of its issue bound, profiles/r03_dual_issue.txt -- for 10 more VGPRs)
         r.c0 = Fq::lmul2(a.c0, b.c0, a.c1, Fq::lneg_op(b.c1));
         r.c1 = Fq::lmul2(a.c0, b.c1, a.c1, b.c0);
         return r;
     }
+    static constexpr bool PAIRS = false;                              // the G2 formulas keep their order (see lmul)
+    static ZK_HD void lmul_pair(const fe2 &a, const fe2 &b, const fe2 &c, const fe2 &d, fe2 &r0, fe2 &r1) { r0 = lmul(a, b); r1 = lmul(c, d); }
+    static ZK_HD void lsqr_pair(const fe2 &a, const fe2 &b, fe2 &r0, fe2 &r1) { r0 = lsqr(a); r1 = lsqr(b); }
     // a*b + c*d in Fq2, one reduction per component
     static ZK_HD fe2 lmul2(const fe2 &a, const fe2 &b, const fe2 &c, const fe2 &d) {
         fe2 r;
@@ -454,7 +555,17 @@ struct Fq2 {
 template <class F>
 struct Curve {
     typedef typename F::elem E;
-    static constexpr int WAVES_PER_SIMD = sizeof(E) > 32 ? 2 : 4;   // VGPR budget: 256 (G2) / 128 (G1)
+    // VGPR budget: 256 (G2, 2 waves/SIMD); G1: 170 (3 waves/SIMD) with the dual-issue pairs of madd -- 156 VGPRs; any pair at 4 waves/SIMD
+    // (128 VGPRs) spills -- or 128 (4 waves/SIMD) without them (ZK_G1_NO_X2).  Same-box A/B at 2^20, accumulation kernels alone:
+    // 1.31 -> 1.245 ms per G1 query (profiles/r03_dual_issue.txt)
+#ifndef ZK_G1_WPS
+#if defined(ZK_NO_X2) || defined(ZK_G1_NO_X2)
+#define ZK_G1_WPS 4
+#else
+#define ZK_G1_WPS 3
+#endif
+#endif
+    static constexpr int WAVES_PER_SIMD = sizeof(E) > 32 ? 2 : ZK_G1_WPS;
     struct alignas(16) Affine { E x, y; };
     struct alignas(16) XYZZ { E X, Y, ZZ, ZZZ; };
 
@@ -495,6 +606,23 @@ struct Curve {
     static ZK_HD XYZZ madd(const XYZZ &p, const Affine &q) {
         if (is_inf(q)) return p;
         if (is_inf(p)) { XYZZ r; r.X = q.x; r.Y = q.y; r.ZZ = F::one(); r.ZZZ = F::one(); return r; }
+        if constexpr (F::PAIRS) {                                      // Fq with dual issue: independent products go in pairs
+            E U2, S2;
+            F::lmul_pair(q.x, p.ZZ, q.y, p.ZZZ, U2, S2);
+            E Pd = F::lsub(U2, p.X), R = F::lsub(S2, p.Y);
+            if (F::lis_zero(Pd)) {
+                if (F::lis_zero(R)) return dbl_affine(q);
+                return infinity();
+            }
+            XYZZ r;
+            E PP, RR, Q, PPP;
+            F::lsqr_pair(Pd, R, PP, RR);
+            F::lmul_pair(p.X, PP, Pd, PP, Q, PPP);
+            F::lmul_pair(p.ZZ, PP, p.ZZZ, PPP, r.ZZ, r.ZZZ);
+            r.X = F::lsub(F::lsub(RR, PPP), F::ldbl(Q));
+            r.Y = F::lmul2(R, F::lsub(Q, r.X), F::lneg_yop(p.Y), PPP);
+            return r;
+        }
         E U2 = F::lmul(q.x, p.ZZ), S2 = F::lmul(q.y, p.ZZZ);
         E Pd = F::lsub(U2, p.X), R = F::lsub(S2, p.Y);
         if (F::lis_zero(Pd)) {

@@ -160,6 +160,7 @@ struct SortView {
     uint32_t nb = 0, entries_bound = 0;             // nb: buckets of the sort (batch x per-proof buckets); entries_bound: upper bound of sorted entries (batch x n_src x W)
     uint32_t batch = 1;                             // proofs sorted together: bucket id = proof * (nb / batch) + digit bucket
     uint32_t remap_src = 0, remap_offset = 0;
+    uint32_t remap_kbits = 0;                       // != 0: the entries are (window << kbits) | scalar instead of window * remap_src + scalar
     const uint32_t *remap_pos = nullptr;            // optional scalar index -> own base index (0xffffffff: absent); else i - remap_offset
 };
 
@@ -207,9 +208,11 @@ struct MsmWork {
     uint32_t tree_levels(uint32_t groups, uint32_t lanes) const;
     const uint32_t *cur_off = nullptr;          // bucket offsets of the sort driving the current reduction
     uint32_t sort_batch = 1;                    // batch of the last enqueue_sort
+    uint32_t sort_kbits = 0;                    // sort-only objects (the shared witness sort): entries carry (window << kbits) | scalar -- set by use_shift_payload()
+    void use_shift_payload() { uint32_t k = 1; while ((1ull << k) < table_n) k++; if (((uint64_t)sh.W << k) < (1ull << 31)) sort_kbits = k; }
     SortView view() const { SortView v; v.sorted = sorted; v.off = off; v.batch = sort_batch; v.nb = sh.nb * sort_batch; v.entries_bound = (uint32_t)((uint64_t)table_n * sh.W * sort_batch); return v; }
     // view for an MSM over scalars [offset, offset + n_dst) of THIS sort (its table has stride n_dst)
-    SortView view_for(uint32_t offset, const uint32_t *pos = nullptr) const { SortView v = view(); v.remap_src = table_n; v.remap_offset = offset; v.remap_pos = pos; return v; }
+    SortView view_for(uint32_t offset, const uint32_t *pos = nullptr) const { SortView v = view(); v.remap_src = table_n; v.remap_offset = offset; v.remap_pos = pos; v.remap_kbits = sort_kbits; return v; }
     typename C::XYZZ finish(uint32_t proof = 0) const { return C::canon(host_result[proof]); }   // device values are loose ([0, 2p)): normalise once
 };
 

@@ -119,7 +119,7 @@ template <class C>
 __global__ void __launch_bounds__(SORT_THREADS)
 k_sort_partition(const fe *__restrict__ scalars, const uint32_t *__restrict__ gather, uint32_t n, uint32_t batch, uint32_t stride, int canonical,
                  uint32_t c, uint32_t W, SortShape ss, const uint32_t *__restrict__ counts,
-                 const uint32_t *__restrict__ bin_base, uint2 *__restrict__ pairs) {
+                 const uint32_t *__restrict__ bin_base, uint2 *__restrict__ pairs, uint32_t kbits) {
     __shared__ uint32_t pos[SORT_MAX_CB];
     for (uint32_t k = threadIdx.x; k < ss.cb; k += blockDim.x) pos[k] = bin_base[k] + counts[(size_t)k * ss.groups + blockIdx.x];
     __syncthreads();
@@ -134,7 +134,9 @@ k_sort_partition(const fe *__restrict__ scalars, const uint32_t *__restrict__ ga
             if (!d) continue;
             const uint32_t b = pr * nbp + d - 1;                        // (proof, bucket)
             uint32_t p = atomicAdd(&pos[b >> ss.fine_bits], 1u);
-            uint2 e; e.x = (w * n + il) | (neg << 31); e.y = b;         // table index of 2^(cw) P_il, sign; bucket
+            // payload: table index of 2^(cw) P_il (own sort: w n + il), or -- a sort that drives OTHER queries' tables -- (w << kbits) | il,
+            // which their accumulation kernels take apart with a shift and a mask instead of a division; sign in bit 31
+            uint2 e; e.x = (kbits ? (w << kbits) | il : w * n + il) | (neg << 31); e.y = b;
             pairs[p] = e;
         }
     }
@@ -189,7 +191,7 @@ template <class C, int Q>
 __global__ void __launch_bounds__(64, C::WAVES_PER_SIMD)
 k_msm_accumulate(const typename C::Affine *__restrict__ table, const uint32_t *__restrict__ sorted,
                  const uint32_t *__restrict__ off, uint32_t nb, ChunkRule rule,
-                 uint32_t remap_src, uint32_t remap_offset, const uint32_t *__restrict__ remap_pos, uint32_t n_dst,
+                 uint32_t remap_src, uint32_t remap_offset, const uint32_t *__restrict__ remap_pos, uint32_t n_dst, uint32_t remap_kbits,
                  typename C::XYZZ *__restrict__ piece) {
     const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x, c = gt / Q, ql = gt % Q;
     const uint32_t total = off[nb], seg = rule.len(total);
@@ -206,7 +208,9 @@ k_msm_accumulate(const typename C::Affine *__restrict__ table, const uint32_t *_
     auto entry_index = [&](uint32_t p) -> uint32_t {             // table index of an entry, or 0xffffffff when it is not this query's
         uint32_t idx = p & 0x7fffffffu;
         if (remap_src) {                                        // entry of another query's sort: (window, scalar) -> own table
-            const uint32_t w = idx / remap_src, i = idx - w * remap_src;
+            uint32_t w, i;
+            if (remap_kbits) { w = idx >> remap_kbits; i = idx & ((1u << remap_kbits) - 1u); }      // (w << kbits) | i: the shared witness sort
+            else { w = idx / remap_src; i = idx - w * remap_src; }
             const uint32_t k = remap_pos ? remap_pos[i] : i - remap_offset;     // unsigned wrap / 0xffffffff = absent
             if (k >= n_dst) return 0xffffffffu;
             idx = w * n_dst + k;
@@ -390,7 +394,7 @@ int MsmWork<C>::enqueue_sort(const fe *scalars, const uint32_t *gather, uint32_t
     ZK_LAUNCH_SYNC(k_sort_colscan<C>, sq.cb, SORT_THREADS, st, counts, sq.groups, bin_total);
     ZK_LAUNCH_SYNC(k_sort_binscan<C>, 1, SORT_THREADS, st, (const uint32_t *)bin_total, sq.cb, bin_base);
     ZK_LAUNCH_SYNC(k_sort_partition<C>, sq.groups, SORT_THREADS, st, scalars, gather, n, batch, stride, canonical, c, W, sq,
-                   (const uint32_t *)counts, (const uint32_t *)bin_base, pairs);
+                   (const uint32_t *)counts, (const uint32_t *)bin_base, pairs, sort_kbits);
     ZK_LAUNCH_SYNC(k_sort_fine<C>, sq.cb, SORT_FINE_THREADS, st, (const uint2 *)pairs, (const uint32_t *)bin_base, sq, nb, off, sorted);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
@@ -437,10 +441,10 @@ int MsmWork<C>::enqueue_reduce(const SortView &v, hipStream_t st, hipStream_t st
     ZK_HIP(hipEventRecord(ev_acc0, st));
     if (sh.quad_acc == 4)
         ZK_LAUNCH((k_msm_accumulate<C, 4>), zk_div_up(max_seg * 4, 64), 64, st, (const typename C::Affine *)table, v.sorted, v.off,
-                  nb, sh.chunk, v.remap_src, v.remap_offset, v.remap_pos, table_n, pieces);
+                  nb, sh.chunk, v.remap_src, v.remap_offset, v.remap_pos, table_n, v.remap_kbits, pieces);
     else
         ZK_LAUNCH((k_msm_accumulate<C, 1>), zk_div_up(max_seg, 64), 64, st, (const typename C::Affine *)table, v.sorted, v.off,
-                  nb, sh.chunk, v.remap_src, v.remap_offset, v.remap_pos, table_n, pieces);
+                  nb, sh.chunk, v.remap_src, v.remap_offset, v.remap_pos, table_n, v.remap_kbits, pieces);
     ZK_HIP(hipEventRecord(ev_acc1, st));
     if (st_tail != st) { ZK_HIP(hipStreamWaitEvent(st_tail, ev_acc1, 0)); st = st_tail; }
     cur_off = v.off;

@@ -692,7 +692,7 @@ static int ctx_build(zk_ctx *c, const zk_pk *pk, const zk_csr *A, const zk_csr *
     const DeviceTables *t = c->tables;
     const bool any_share = t->share_A || t->share_B || t->share_L;
     const uint32_t KB = c->max_batch;
-    if (any_share) ZK_TRY(c->mW.alloc(t->win_n, t->cW, nullptr, nullptr, /*sort_only=*/true, KB));
+    if (any_share) { ZK_TRY(c->mW.alloc(t->win_n, t->cW, nullptr, nullptr, /*sort_only=*/true, KB)); c->mW.use_shift_payload(); }
     ZK_TRY(c->mA.alloc(c->rA.n(), t->cA, t->tA, t->share_A ? &c->mW.sh : nullptr, false, KB));
     ZK_TRY(c->mH.alloc(c->rH.n(), t->cH, t->tH, nullptr, false, KB));
     ZK_TRY(c->mL.alloc(c->rL.n(), t->cL, t->tL, t->share_L ? &c->mW.sh : nullptr, false, KB));
@@ -929,6 +929,10 @@ static int prove_enqueue(zk_ctx *c, const uint64_t *witness, int canonical, int 
         if (split_h) ZK_HIP(hipEventRecord(c->ev_sort_h, hs));
         return ZK_OK;
     };
+    // Two other places for the H pipeline of ONE large synchronous proof were measured and are not taken (tools/dev_sync_latency.py,
+    // 2^20 / 2^18): FIRST and alone, the accumulations released when it is done -- 11.97 / 3.94 ms against 11.09 / 3.76: beside the
+    // accumulations it crawls (7.9 ms instead of 1.35 in the rocprofv3 timeline, profiles/r03_sync_timeline_2p20.txt) but its memory-bound
+    // kernels do overlap with them; its launches queued right behind the B-query's instead of behind the L-query's (host order) -- no change.
     if (phase != PHASE_H) {
     if (split_h) { ZK_HIP(hipEventRecord(c->ev_up, m)); ZK_HIP(hipStreamWaitEvent(hs, c->ev_up, 0)); }
     if (t->share_A || t->share_B || t->share_L) {               // one sort of the witness digits of the window

@@ -583,6 +583,41 @@ def test_option2_split_witness_map_entry_points_on_one_device(hip, oracle, logm)
         c.close()
 
 
+def test_assembly_postpass_off_and_on_give_identical_results(hip, oracle):
+    """The default build passes the device assembly through tools/strip_asm_nops.py (drops the s_nop hipcc pads behind the
+    inline-asm statements of the field arithmetic).  The same sources built with POSTPASS=0 (variants/nopostpass, made by
+    __graft_entry__.build()) must give the same bytes: a G1 and a G2 multi-exponentiation and a proof, in a child process."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = os.path.join(root, "variants", "nopostpass", "libzkhip.so")
+    assert os.path.exists(so), "variants/nopostpass/libzkhip.so missing: run __graft_entry__.build()"
+    code = '''
+import sys, json, numpy as np
+sys.path[:0] = [%r, %r, %r]
+import oracle_lib as O
+from helpers import rand_scalars, tiled_bases
+from ethsnarks_amd import prover as P, r1cs as R, fields as F
+P.load_library(%r)
+out = {}
+for g2 in (False, True):
+    s = F.fr_to_mont(rand_scalars(5000, 3, ones_every=7, zeros_every=13))
+    out["msm_g2" if g2 else "msm_g1"] = P.msm(tiled_bases(O, 5000, g2=g2), s, g2=g2).tolist()
+r, w = R.synthetic_chain((1 << 12) - 2, 1)
+pk, _ = P.keygen(r, seed=4)
+out["proof"] = P.prove(P.ProverContext(pk, r), F.fr_to_mont(w))
+print("RESULT" + json.dumps(out))
+'''
+    outs = []
+    for lib in (so, os.path.join(root, "ethsnarks_amd", "libzkhip.so")):
+        p = subprocess.run([sys.executable, "-c", code % (root, os.path.join(root, "tests"), os.path.join(root, "oracle"), lib)], capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs.append([l for l in p.stdout.splitlines() if l.startswith("RESULT")][0])
+    assert outs[0] == outs[1]
+    r, w = R.synthetic_chain((1 << 12) - 2, 1)
+    pk_o, _ = oracle.keygen(r, seed=4)
+    assert json.loads(outs[0][6:])["proof"] == oracle.prove(pk_o, r, F.fr_to_mont(w))[0]
+
+
 def test_stub_test_proof_verify_and_static_triple(hip):
     """stub_test_proof_verify (src/stubs.cpp:135-148) through the C ABI on the GPU; zk_verify on the reference's vector"""
     import os

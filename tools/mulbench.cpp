@@ -24,6 +24,13 @@ __global__ void __launch_bounds__(256, WPS) k_mul2(fe *io, int iters) {         
     io[t] = Fq::ladd(Fq::ladd(a, b), Fq::ladd(c, d));
 }
 template <int WPS>
+__global__ void __launch_bounds__(256, WPS) k_mul2x(fe *io, int iters) {         // two independent chains per thread, dual-issue statements (lmul_x2)
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    fe a = io[t], b = io[t + gridDim.x * blockDim.x], c = Fq::ladd(a, b), d = Fq::ladd(b, b);
+    for (int i = 0; i < iters; i++) { Fq::lmul_x2(a, b, c, d, a, c); Fq::lmul_x2(b, a, d, c, b, d); }
+    io[t] = Fq::ladd(Fq::ladd(a, b), Fq::ladd(c, d));
+}
+template <int WPS>
 __global__ void __launch_bounds__(256, WPS) k_dot2(fe *io, int iters) {          // lmul2 chain (what an Fq2 product is made of)
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     fe a = io[t], b = io[t + gridDim.x * blockDim.x], c = Fq::ladd(a, b), d = Fq::ladd(b, b);
@@ -83,6 +90,7 @@ int main(int argc, char **argv) {
         printf("%-10s %-14s %d waves/SIMD: %8.3f ms  %7.2f G Fq-mul-equiv/s\n", tag, name, wps, ms, (double)mulsper * g * block * it / ms * 1e-6); }
     RUN("mul chain", k_mul1, 1, 2) RUN("mul chain", k_mul1, 2, 2) RUN("mul chain", k_mul1, 4, 2) RUN("mul chain", k_mul1, 8, 2)
     RUN("mul 2-ilp", k_mul2, 1, 4) RUN("mul 2-ilp", k_mul2, 2, 4) RUN("mul 2-ilp", k_mul2, 4, 4)
+    RUN("mul x2", k_mul2x, 1, 4) RUN("mul x2", k_mul2x, 2, 4) RUN("mul x2", k_mul2x, 3, 4) RUN("mul x2", k_mul2x, 4, 4)
     RUN("dot2 chain", k_dot2, 2, 2) RUN("dot2 chain", k_dot2, 4, 2)
     RUN("dot2 2-ilp", k_dot2x2, 2, 4) RUN("dot2 2-ilp", k_dot2x2, 4, 4)
     RUN("Fq2 mul chain", k_fq2mul, 2, 4) RUN("Fq2 mul chain", k_fq2mul, 4, 4)
