@@ -25,9 +25,7 @@ constexpr int NTT_THREADS = 512;
 constexpr int NTT_MIN_LOGC = 2;                  // >= 4 columns = 128 contiguous bytes (one cache line) per tile row
 
 static ZK_HD uint32_t bitrev32(uint32_t v, uint32_t bits) {
-    uint32_t r = 0;
-    for (uint32_t i = 0; i < bits; i++) { r = (r << 1) | (v & 1); v >>= 1; }
-    return r;
+    return bits ? __builtin_bitreverse32(v) >> (32 - bits) : 0;          // v_bfrev_b32 + shift (bits <= 28)
 }
 
 // One pass = stages s0+1 .. s0+k of the decimation-in-time transform.
@@ -38,12 +36,20 @@ static ZK_HD uint32_t bitrev32(uint32_t v, uint32_t bits) {
 // post[] (nullable) multiplies output element i by post[i]                   (1/m, g^-i/m, ...)
 // blockIdx.y selects one of several equal-size vectors laid out `batch_stride` elements apart (the A, B and C
 // polynomials of the witness map are transformed by one launch per pass)
+// Fused steps of the witness map (NttFuse; all optional, wave-uniform branches):
+//   in2      the transform's input is the pointwise product in[i] * in2[i]  (A * B on the coset; first pass only)
+//   post_alt vectors blockIdx.y >= alt_from are scaled by post_alt[] instead of post[]  (the C polynomial of a batched inverse)
+//   sub      out[i] = v * post[i] - sub[i]  (last pass; needs post)
+struct NttFuse { const fe *in2 = nullptr; const fe *post_alt = nullptr; uint32_t alt_from = 0xffffffffu; const fe *sub = nullptr; };
 __global__ void __launch_bounds__(NTT_THREADS)
 k_ntt_pass(const fe *__restrict__ in, fe *__restrict__ out, const fe *__restrict__ tw,
            uint32_t logm, uint32_t s0, uint32_t k, uint32_t logc, int bitrev_load,
-           const fe *__restrict__ pre, const fe *__restrict__ post, uint32_t batch_stride) {
+           const fe *__restrict__ pre, const fe *__restrict__ post, uint32_t batch_stride, NttFuse fuse, int last_pass) {
     __shared__ uint32_t sh[8][NTT_TILE];
     in += (size_t)blockIdx.y * batch_stride; out += (size_t)blockIdx.y * batch_stride;
+    if (fuse.in2) fuse.in2 += (size_t)blockIdx.y * batch_stride;
+    if (fuse.sub) fuse.sub += (size_t)blockIdx.y * batch_stride;
+    if (fuse.post_alt && blockIdx.y >= fuse.alt_from) post = fuse.post_alt;
     const uint32_t tile = 1u << (k + logc), ncol = 1u << logc;
     const uint32_t nlb = (1u << s0) >> logc;                  // column groups per high index
     const uint32_t lb = blockIdx.x & (nlb - 1), h = blockIdx.x / nlb;
@@ -53,6 +59,7 @@ k_ntt_pass(const fe *__restrict__ in, fe *__restrict__ out, const fe *__restrict
         uint32_t idx = base | ((e >> logc) << s0) | (e & (ncol - 1));
         uint32_t src = bitrev_load ? bitrev32(idx, logm) : idx;
         fe v = in[src];
+        if (fuse.in2) v = Fr::mul(v, fuse.in2[src]);
         if (pre) v = Fr::mul(v, pre[src]);
 #pragma unroll
         for (int l = 0; l < 8; l++) sh[l][e] = v.l[l];
@@ -68,8 +75,10 @@ k_ntt_pass(const fe *__restrict__ in, fe *__restrict__ out, const fe *__restrict
             fe u, v;
 #pragma unroll
             for (int l = 0; l < 8; l++) { u.l[l] = sh[l][eu]; v.l[l] = sh[l][ev]; }
-            if (S > 1) v = Fr::mul(v, tw[(size_t)j << (logm - S)]);   // stage 1: every twiddle is w^0 = 1 (uniform branch)
-            fe a = Fr::add(u, v), b = Fr::sub(u, v);
+            // butterflies in the loose domain [0, 2p) (bn254.hpp: no conditional subtraction behind the product, sums and differences
+            // fold by 2p): 25 instructions less per butterfly; the last pass normalises what it stores
+            if (S > 1) v = Fr::lmul(v, tw[(size_t)j << (logm - S)]);   // stage 1: every twiddle is w^0 = 1 (uniform branch)
+            fe a = Fr::ladd(u, v), b = Fr::lsub(u, v);
 #pragma unroll
             for (int l = 0; l < 8; l++) { sh[l][eu] = a.l[l]; sh[l][ev] = b.l[l]; }
         }
@@ -80,7 +89,9 @@ k_ntt_pass(const fe *__restrict__ in, fe *__restrict__ out, const fe *__restrict
         fe v;
 #pragma unroll
         for (int l = 0; l < 8; l++) v.l[l] = sh[l][e];
-        if (post) v = Fr::mul(v, post[idx]);
+        if (post) v = Fr::mul(v, post[idx]);                    // strict product: canonical whatever the (loose) input
+        else if (last_pass) v = Fr::canon(v);
+        if (fuse.sub) v = Fr::sub(v, fuse.sub[idx]);
         out[idx] = v;
     }
 }
@@ -95,13 +106,6 @@ __global__ void k_fill_geometric(fe *out, uint32_t n, fe g, fe s) {
     for (uint32_t i = i0; i < end; i++) { out[i] = t; t = Fr::mul(t, g); }
 }
 
-// H on the coset: out[i] = (a[i] * b[i] - c[i]) * zinv     (divide_by_Z_on_coset fused); out may be a
-__global__ void k_pointwise_h(fe *out, const fe *a, const fe *b, const fe *c, fe zinv, uint32_t m) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
-    out[i] = Fr::mul(Fr::sub(Fr::mul(a[i], b[i]), c[i]), zinv);
-}
-
 struct NttTables {
     uint32_t logm = 0;
     fe *tw_fwd = nullptr, *tw_inv = nullptr;   // m/2 each
@@ -109,6 +113,8 @@ struct NttTables {
     fe *inv_m = nullptr;                       // 1/m            (iFFT post-scale)
     fe *icoset = nullptr;                      // g^-i / m       (icosetFFT post-scale)
     fe *inv_then_coset = nullptr;              // g^i / m        (iFFT followed by cosetFFT, fused)
+    fe *inv_m_zinv = nullptr;                  // zinv / m       (iFFT of C, pre-divided by Z on the coset)
+    fe *icoset_zinv = nullptr;                 // g^-i zinv / m  (icosetFFT and the division by Z on the coset, fused)
     fe zinv;                                   // (g^m - 1)^-1
 };
 
@@ -128,6 +134,8 @@ static inline int ntt_tables_free(NttTables &t) {
     if (t.inv_m) hipFree(t.inv_m);
     if (t.icoset) hipFree(t.icoset);
     if (t.inv_then_coset) hipFree(t.inv_then_coset);
+    if (t.inv_m_zinv) hipFree(t.inv_m_zinv);
+    if (t.icoset_zinv) hipFree(t.icoset_zinv);
     t = NttTables();
     return ZK_OK;
 }
@@ -142,6 +150,8 @@ static inline int ntt_tables_create(NttTables &t, uint32_t logm, hipStream_t st)
     ZK_HIP(hipMalloc(&t.inv_m, sizeof(fe) * m));
     ZK_HIP(hipMalloc(&t.icoset, sizeof(fe) * m));
     ZK_HIP(hipMalloc(&t.inv_then_coset, sizeof(fe) * m));
+    ZK_HIP(hipMalloc(&t.inv_m_zinv, sizeof(fe) * m));
+    ZK_HIP(hipMalloc(&t.icoset_zinv, sizeof(fe) * m));
     const fe w = fr_domain_root(logm), wi = Fr::inv(w), g = Fr::from_u64(5), gi = Fr::inv(g);
     const fe mi = Fr::inv(Fr::from_u64(m)), one = Fr::one();
     t.zinv = Fr::inv(Fr::sub(Fr::pow_u64(g, m), one));
@@ -155,6 +165,8 @@ static inline int ntt_tables_create(NttTables &t, uint32_t logm, hipStream_t st)
     fill(t.inv_m, m, one, mi);
     fill(t.icoset, m, gi, mi);
     fill(t.inv_then_coset, m, g, mi);
+    fill(t.inv_m_zinv, m, one, Fr::mul(mi, t.zinv));
+    fill(t.icoset_zinv, m, gi, Fr::mul(mi, t.zinv));
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
@@ -162,28 +174,33 @@ static inline int ntt_tables_create(NttTables &t, uint32_t logm, hipStream_t st)
 // out <- transform(in); in and out must be different buffers (pass 0 permutes).  `pre`/`post` as in k_ntt_pass.
 // batch > 1: `batch` vectors, `stride` elements apart in both in and out, one launch per pass.
 static inline int ntt_run(const NttTables &t, const fe *in, fe *out, bool inverse,
-                          const fe *pre, const fe *post, hipStream_t st, uint32_t batch = 1, uint32_t stride = 0) {
+                          const fe *pre, const fe *post, hipStream_t st, uint32_t batch = 1, uint32_t stride = 0, NttFuse fuse = NttFuse()) {
     const uint32_t logm = t.logm, m = 1u << logm;
     const fe *tw = inverse ? t.tw_inv : t.tw_fwd;
     if (logm == 0) {   // size-1 transform is the identity (times scaling)
         uint32_t k0 = 0;
-        ZK_LAUNCH_SYNC(k_ntt_pass, dim3(1, batch), NTT_THREADS, st, in, out, tw, logm, 0u, k0, 0u, 1, pre, post, stride);
+        ZK_LAUNCH_SYNC(k_ntt_pass, dim3(1, batch), NTT_THREADS, st, in, out, tw, logm, 0u, k0, 0u, 1, pre, post, stride, fuse, 1);
         return ZK_OK;
     }
     const uint32_t k0 = logm < (uint32_t)NTT_TILE_LOG ? logm : NTT_TILE_LOG;
     uint32_t rem = logm - k0;
     const uint32_t kmax = NTT_TILE_LOG - NTT_MIN_LOGC;
     uint32_t npass = (rem + kmax - 1) / kmax;
+    NttFuse first = fuse, later = fuse;                        // in2 belongs to the first pass, post / post_alt / sub to the last
+    later.in2 = nullptr;
+    if (rem != 0) { first.post_alt = nullptr; first.sub = nullptr; }
     ZK_LAUNCH_SYNC(k_ntt_pass, dim3(m >> k0, batch), NTT_THREADS, st, in, out, tw, logm, 0u, k0, 0u, 1, pre,
-                   rem == 0 ? post : (const fe *)nullptr, stride);
+                   rem == 0 ? post : (const fe *)nullptr, stride, first, rem == 0 ? 1 : 0);
     uint32_t s0 = k0;
     while (rem) {
         uint32_t k = (rem + npass - 1) / npass;
         uint32_t logc = NTT_TILE_LOG - k;
         if (logc > s0) logc = s0;
         rem -= k; npass--;
+        NttFuse f = later;
+        if (rem != 0) { f.post_alt = nullptr; f.sub = nullptr; }
         ZK_LAUNCH_SYNC(k_ntt_pass, dim3(m >> (k + logc), batch), NTT_THREADS, st, (const fe *)out, out, tw, logm, s0, k, logc, 0,
-                       (const fe *)nullptr, rem == 0 ? post : (const fe *)nullptr, stride);
+                       (const fe *)nullptr, rem == 0 ? post : (const fe *)nullptr, stride, f, rem == 0 ? 1 : 0);
         s0 += k;
     }
     ZK_HIP(hipGetLastError());

@@ -796,10 +796,17 @@ static int enqueue_compute_h(zk_ctx *c, hipStream_t st) {
     ZK_TRY(c->cC.enqueue(c->d_w, cc, st, k, ws, m));
     ZK_LAUNCH(k_set_input_rows, dim3(zk_div_up(c->nIn + 1, 64), k), 64, st, a, (const fe *)c->d_w, c->nC, c->nIn, ws, m);
     // all 3 k polynomials go through each pass together (blockIdx.y): fewer, larger launches
-    ZK_TRY(ntt_run(c->tab, a, c->d_t, true, nullptr, c->tab.inv_then_coset, st, 3 * k, m));   // iFFT, then x g^i (cosetFFT pre-scale)
-    ZK_TRY(ntt_run(c->tab, c->d_t, a, false, nullptr, nullptr, st, 3 * k, m));               // FFT -> evaluations on the coset
-    ZK_LAUNCH(k_pointwise_h, zk_div_up((uint64_t)m * k, 256), 256, st, a, (const fe *)a, (const fe *)b, (const fe *)cc, c->tab.zinv, m * k);
-    ZK_TRY(ntt_run(c->tab, a, c->d_t, true, nullptr, c->tab.icoset, st, k, m));          // icosetFFT
+    // SIX transforms, not the reference's seven (libsnark: iFFT and cosetFFT of A, B and C, divide by Z on the coset, icosetFFT): C never
+    // goes to the coset.  With P = A B, icosetFFT(P on the coset) is P mod (x^m - g^m) = Z(g) H + C for every witness (deg H, deg C < m,
+    // Z = x^m - 1, Z on the coset is the constant Z(g) = g^m - 1), so  h = icosetFFT(A B) / Z(g) - C / Z(g):  the same field elements
+    // (the coefficients are unique), one forward transform and one pass over four vectors less.  The product A B is formed when the
+    // last transform loads its input, C / Z(g) comes out of its iFFT (scaled there) and is subtracted when the last transform stores.
+    (void)cc;
+    NttFuse cscale; cscale.post_alt = c->tab.inv_m_zinv; cscale.alt_from = 2 * k;                     // vectors [2k, 3k) are the C polynomials
+    ZK_TRY(ntt_run(c->tab, a, c->d_t, true, nullptr, c->tab.inv_then_coset, st, 3 * k, m, cscale));   // iFFT of A, B (x g^i / m: cosetFFT pre-scale) and of C (x 1 / (m Z(g)))
+    ZK_TRY(ntt_run(c->tab, c->d_t, a, false, nullptr, nullptr, st, 2 * k, m));                        // FFT: A, B on the coset
+    NttFuse last; last.in2 = b; last.sub = c->d_t + 2 * (size_t)m * k;
+    ZK_TRY(ntt_run(c->tab, a, c->d_t, true, nullptr, c->tab.icoset_zinv, st, k, m, last));            // icosetFFT of A B, / Z(g), - C / Z(g)
     if (k == 1) ZK_HIP(hipMemcpyAsync(c->h_tail, c->d_t + (m - 1), 32, hipMemcpyDeviceToHost, st));
     else ZK_HIP(hipMemcpy2DAsync(c->h_tail, 32, c->d_t + (m - 1), 32 * (size_t)m, 32, k, hipMemcpyDeviceToHost, st));
     ZK_HIP(hipGetLastError());
@@ -816,6 +823,7 @@ static int enqueue_chain(zk_ctx *c, int which) {
     const DevCsr &M = which == 0 ? c->cA : which == 1 ? c->cB : c->cC;
     ZK_TRY(M.enqueue(c->d_w, p, st, 1, ws, m));
     if (which == 0) ZK_LAUNCH(k_set_input_rows, dim3(zk_div_up(c->nIn + 1, 64), 1), 64, st, p, (const fe *)c->d_w, c->nC, c->nIn, ws, m);
+    if (which == 2) return ntt_run(c->tab, p, tmp, true, nullptr, c->tab.inv_m_zinv, st);      // C stays in coefficient form, / Z(g) (enqueue_compute_h): at d_t + 2 m
     ZK_TRY(ntt_run(c->tab, p, tmp, true, nullptr, c->tab.inv_then_coset, st));
     ZK_TRY(ntt_run(c->tab, tmp, p, false, nullptr, nullptr, st));
     return ZK_OK;
@@ -824,10 +832,9 @@ static int enqueue_chain(zk_ctx *c, int which) {
 static int enqueue_h_from_chains(zk_ctx *c, const fe *a, const fe *b, const fe *cc) {
     hipStream_t st = c->s_main;
     const uint32_t m = c->m;
-    fe *tmp = c->d_a + 3 * (size_t)m * c->max_batch - m;           // the last m elements of the polynomial buffer: free when batch = 1
-    if (c->max_batch == 1) tmp = c->d_t + m;                        // (d_t holds 3 m elements; h goes to its first m)
-    ZK_LAUNCH(k_pointwise_h, zk_div_up(m, 256), 256, st, tmp, a, b, cc, c->tab.zinv, m);
-    ZK_TRY(ntt_run(c->tab, tmp, c->d_t, true, nullptr, c->tab.icoset, st));
+    if (cc >= c->d_t && cc < c->d_t + m) return fail(ZK_ERR_ARG, "zk_h_from_chains_submit: the C chain overlaps the context's h buffer");
+    NttFuse last; last.in2 = b; last.sub = cc;                      // a, b: coset evaluations; cc: coefficients of C / Z(g)
+    ZK_TRY(ntt_run(c->tab, a, c->d_t, true, nullptr, c->tab.icoset_zinv, st, 1, m, last));
     ZK_HIP(hipMemcpyAsync(c->h_tail, c->d_t + (m - 1), 32, hipMemcpyDeviceToHost, st));
     return ZK_OK;
 }
@@ -1078,7 +1085,10 @@ extern "C" int zk_chain_submit(zk_ctx *c, const uint64_t *witness, int canonical
     ZK_TRY(upload_witness(c, witness, canonical));
     return enqueue_chain(c, which);
 }
-extern "C" const void *zk_chain_device(const zk_ctx *c, int which) { return (c && which >= 0 && which <= 2) ? c->d_a + (size_t)which * c->m : nullptr; }
+extern "C" const void *zk_chain_device(const zk_ctx *c, int which) {
+    if (!c || which < 0 || which > 2) return nullptr;
+    return which == 2 ? c->d_t + 2 * (size_t)c->m : c->d_a + (size_t)which * c->m;       // A, B: coset evaluations; C: coefficients / Z(g)
+}
 extern "C" int zk_h_from_chains_submit(zk_ctx *c, const void *dA, const void *dB, const void *dC) {
     if (!c || !dA || !dB || !dC) return fail(ZK_ERR_ARG, "null argument");
     if (c->in_flight && !c->awaiting_h) return fail(ZK_ERR_ARG, "a proof is in flight on this context (collect it first)");

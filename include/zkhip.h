@@ -199,7 +199,8 @@ int zk_prove_batch_submit_resident(zk_ctx *ctx, const void *d_witnesses, uint32_
 int zk_prove_batch_collect(zk_ctx *ctx, zk_partials *out, uint32_t k, zk_timings *t);
 /* ---- sharded latency mode, SURVEY 8(e) option 2: the three transform chains of the witness map (row evaluations of A, B or C,
  * iFFT, cosetFFT) run on three different ranks instead of being replicated on all of them.
- *   zk_chain_submit         queue chain `which` (0 A, 1 B, 2 C) of this witness; its m coset evaluations end up at zk_chain_device
+ *   zk_chain_submit         queue chain `which` (0 A, 1 B, 2 C) of this witness; its m results end up at zk_chain_device (A, B: evaluations on
+ *                           the coset; C: coefficients divided by Z on the coset -- the witness map here needs six transforms, C never goes to the coset)
  *   zk_h_from_chains_submit queue (a b - c) / Z on the coset + icosetFFT from three chain buffers in THIS device's memory
  *                           (received from the other ranks); h ends up at zk_h_device (m elements)
  *   zk_chain_wait           wait for what was queued (check_degree: ZK_ERR_DEGREE unless h[m-1] = 0)
