@@ -154,7 +154,15 @@ k_sort_fine(const uint2 *__restrict__ pairs, const uint32_t *__restrict__ bin_ba
     const uint32_t fmask = ss.fb - 1;
     for (uint32_t k = t; k < ss.fb; k += T) cnt[k] = 0;
     __syncthreads();
-    for (uint32_t e = r0 + t; e < r1; e += T) atomicAdd(&cnt[pairs[e].y & fmask], 1u);
+    // four independent loads per thread and round trip: the pass is a chain of dependent global-load latencies (one workgroup per
+    // CU walks ~60 K pairs), not bandwidth
+    for (uint32_t e = r0 + t; e < r1; e += 4 * T) {
+        uint32_t y[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) y[u] = e + u * T < r1 ? pairs[e + u * T].y : 0xffffffffu;
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) if (e + u * T < r1) atomicAdd(&cnt[y[u] & fmask], 1u);
+    }
     __syncthreads();
     // exclusive scan of cnt[0..fb): thread-serial runs + Hillis-Steele over the run sums
     const uint32_t per = (ss.fb + T - 1) / T, k0 = t * per, k1 = (k0 + per < ss.fb) ? k0 + per : ss.fb;
@@ -177,9 +185,12 @@ k_sort_fine(const uint2 *__restrict__ pairs, const uint32_t *__restrict__ bin_ba
     }
     if (bin + 1 == gridDim.x && t == 0) off[nb] = r1;       // all entries
     __syncthreads();
-    for (uint32_t e = r0 + t; e < r1; e += T) {
-        const uint2 pr = pairs[e];
-        sorted[atomicAdd(&cur[pr.y & fmask], 1u)] = pr.x;
+    for (uint32_t e = r0 + t; e < r1; e += 4 * T) {
+        uint2 pr[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) if (e + u * T < r1) pr[u] = pairs[e + u * T];
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) if (e + u * T < r1) sorted[atomicAdd(&cur[pr[u].y & fmask], 1u)] = pr[u].x;
     }
 }
 

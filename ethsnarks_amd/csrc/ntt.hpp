@@ -21,11 +21,22 @@ namespace zk {
 
 constexpr int NTT_TILE_LOG = 11;                 // 2048 elements = 64 KiB of LDS per workgroup
 constexpr int NTT_TILE = 1 << NTT_TILE_LOG;
-constexpr int NTT_THREADS = 512;
+// threads per workgroup: the 64 KiB tile allows two workgroups per CU, so 1024 threads give 8 waves per SIMD (48 VGPRs) where 512 gave 4:
+// the six transforms at 2^20 0.873 -> 0.840 ms, at 2^18 0.305 -> 0.282 ms (tools/ntt_bench, same box; 256: 0.956 / 0.361)
+#ifndef ZK_NTT_THREADS
+#define ZK_NTT_THREADS 1024
+#endif
+constexpr int NTT_THREADS = ZK_NTT_THREADS;
 constexpr int NTT_MIN_LOGC = 2;                  // >= 4 columns = 128 contiguous bytes (one cache line) per tile row
 
 static ZK_HD uint32_t bitrev32(uint32_t v, uint32_t bits) {
+#if defined(__clang__)
     return bits ? __builtin_bitreverse32(v) >> (32 - bits) : 0;          // v_bfrev_b32 + shift (bits <= 28)
+#else
+    uint32_t r = 0;                                                      // (g++: the CPU emulation of tests/emul)
+    for (uint32_t i = 0; i < bits; i++) { r = (r << 1) | (v & 1); v >>= 1; }
+    return r;
+#endif
 }
 
 // One pass = stages s0+1 .. s0+k of the decimation-in-time transform.
