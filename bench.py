@@ -51,7 +51,7 @@ WITNESS_NOTE = {
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 MAD_LANE_OPS_PER_CLK_CU = 43.4  # measured v_mad_u64_u32 rate, tools/microbench (profiles/r01_microbench.txt)
 MADS_PER_G2_MADD = 6 * 400 + 2 * 272 + 656   # = 3600: 6 Fq2 products (2 x (2 x 64 + 72)), 2 Fq2 squarings (2 x 136), one 2-term Fq2 dot product (2 x (4 x 64 + 72))
-PMC_PROFILE = os.path.join("profiles", "r02_pmc_traffic.json")
+PMC_PROFILE = os.path.join("profiles", "r03_pmc_traffic.json")
 
 
 def main():
