@@ -555,17 +555,13 @@ struct Fq2 {
 template <class F>
 struct Curve {
     typedef typename F::elem E;
-    // VGPR budget: 256 (G2, 2 waves/SIMD); G1: 170 (3 waves/SIMD) with the dual-issue pairs of madd -- 156 VGPRs; any pair at 4 waves/SIMD
-    // (128 VGPRs) spills -- or 128 (4 waves/SIMD) without them (ZK_G1_NO_X2).  Same-box A/B at 2^20, accumulation kernels alone:
-    // 1.31 -> 1.245 ms per G1 query (profiles/r03_dual_issue.txt)
-#ifndef ZK_G1_WPS
-#if defined(ZK_NO_X2) || defined(ZK_G1_NO_X2)
-#define ZK_G1_WPS 4
-#else
-#define ZK_G1_WPS 3
-#endif
-#endif
-    static constexpr int WAVES_PER_SIMD = sizeof(E) > 32 ? 2 : ZK_G1_WPS;
+    // VGPR budget: 256 (G2, 2 waves/SIMD), 128 (G1, 4 waves/SIMD).  The machine-filling G1 accumulations use the mixed addition with
+    // dual-issue product pairs (madd_pairs), which needs 156 VGPRs: 3 waves/SIMD (any pair at 4 waves/SIMD spills).  Same-box A/B at
+    // 2^20, accumulation kernels alone: 1.31 -> 1.245 ms per G1 query, bench +1.4 % (profiles/r03_dual_issue.txt); latency-sized
+    // multi-exponentiations keep the plain form at 4 waves/SIMD (fewer resident threads mean longer chunks: synchronous 2^17 proof
+    // 2.38 -> 2.59 ms with the pairs form) -- MsmShape::acc_pairs.
+    static constexpr int WAVES_PER_SIMD = sizeof(E) > 32 ? 2 : 4;
+    static constexpr int WAVES_PER_SIMD_PAIRS = sizeof(E) > 32 ? 2 : 3;
     struct alignas(16) Affine { E x, y; };
     struct alignas(16) XYZZ { E X, Y, ZZ, ZZZ; };
 
@@ -606,23 +602,6 @@ struct Curve {
     static ZK_HD XYZZ madd(const XYZZ &p, const Affine &q) {
         if (is_inf(q)) return p;
         if (is_inf(p)) { XYZZ r; r.X = q.x; r.Y = q.y; r.ZZ = F::one(); r.ZZZ = F::one(); return r; }
-        if constexpr (F::PAIRS) {                                      // Fq with dual issue: independent products go in pairs
-            E U2, S2;
-            F::lmul_pair(q.x, p.ZZ, q.y, p.ZZZ, U2, S2);
-            E Pd = F::lsub(U2, p.X), R = F::lsub(S2, p.Y);
-            if (F::lis_zero(Pd)) {
-                if (F::lis_zero(R)) return dbl_affine(q);
-                return infinity();
-            }
-            XYZZ r;
-            E PP, RR, Q, PPP;
-            F::lsqr_pair(Pd, R, PP, RR);
-            F::lmul_pair(p.X, PP, Pd, PP, Q, PPP);
-            F::lmul_pair(p.ZZ, PP, p.ZZZ, PPP, r.ZZ, r.ZZZ);
-            r.X = F::lsub(F::lsub(RR, PPP), F::ldbl(Q));
-            r.Y = F::lmul2(R, F::lsub(Q, r.X), F::lneg_yop(p.Y), PPP);
-            return r;
-        }
         E U2 = F::lmul(q.x, p.ZZ), S2 = F::lmul(q.y, p.ZZZ);
         E Pd = F::lsub(U2, p.X), R = F::lsub(S2, p.Y);
         if (F::lis_zero(Pd)) {
@@ -637,6 +616,30 @@ struct Curve {
         r.X = F::lsub(F::lsub(F::lsqr(R), PPP), F::ldbl(Q));
         r.Y = F::lmul2(R, F::lsub(Q, r.X), F::lneg_yop(p.Y), PPP);        // R (Q - X3) - Y1 PPP: one reduction
         return r;
+    }
+    // the same sum with the independent products of the formula issued in pairs (Field::lmul_pair: dual-issue statements over Fq;
+    // over Fq2 -- and on the host -- it is madd)
+    static ZK_HD XYZZ madd_pairs(const XYZZ &p, const Affine &q) {
+        if constexpr (!F::PAIRS) return madd(p, q);
+        else {
+        if (is_inf(q)) return p;
+        if (is_inf(p)) { XYZZ r; r.X = q.x; r.Y = q.y; r.ZZ = F::one(); r.ZZZ = F::one(); return r; }
+        E U2, S2;
+        F::lmul_pair(q.x, p.ZZ, q.y, p.ZZZ, U2, S2);
+        E Pd = F::lsub(U2, p.X), R = F::lsub(S2, p.Y);
+        if (F::lis_zero(Pd)) {
+            if (F::lis_zero(R)) return dbl_affine(q);
+            return infinity();
+        }
+        XYZZ r;
+        E PP, RR, Q, PPP;
+        F::lsqr_pair(Pd, R, PP, RR);
+        F::lmul_pair(p.X, PP, Pd, PP, Q, PPP);
+        F::lmul_pair(p.ZZ, PP, p.ZZZ, PPP, r.ZZ, r.ZZZ);
+        r.X = F::lsub(F::lsub(RR, PPP), F::ldbl(Q));
+        r.Y = F::lmul2(R, F::lsub(Q, r.X), F::lneg_yop(p.Y), PPP);
+        return r;
+        }
     }
     // p + q (add-2008-s)
     static ZK_HD XYZZ add(const XYZZ &p, const XYZZ &q) {
@@ -746,6 +749,8 @@ struct Curve {
     // Q lanes per logical thread: the plain forms for Q = 1, the quad forms for Q = 4
     template <int Q> static ZK_HD XYZZ addQ(const XYZZ &p, const XYZZ &q, uint32_t ql) { if constexpr (Q == 4) return add_q(p, q, ql); else return add(p, q); }
     template <int Q> static ZK_HD XYZZ maddQ(const XYZZ &p, const Affine &q, uint32_t ql) { if constexpr (Q == 4) return madd_q(p, q, ql); else return madd(p, q); }
+    // Q = 1: plain, 4: quad-cooperative, 2: one lane, product pairs (the machine-filling G1 accumulations)
+    template <int Q> static ZK_HD XYZZ maddV(const XYZZ &p, const Affine &q, uint32_t ql) { if constexpr (Q == 2) return madd_pairs(p, q); else return maddQ<Q>(p, q, ql); }
     template <int Q> static ZK_HD XYZZ mul_smallQ(const XYZZ &p, uint32_t k, uint32_t ql) { if constexpr (Q == 4) return mul_small_q(p, k, ql); else return mul_small(p, k); }
 
     // The formulas above run in the loose domain [0, 2p) of the field (no-op on the host).  to_affine normalises

@@ -103,6 +103,7 @@ struct MsmShape {
     ChunkRule chunk;
     uint32_t quad = 1;      // lanes per logical thread in the bucket-reduction kernels: 1, or 4 (Curve::*_q) for latency-bound sizes
     uint32_t quad_acc = 1;  // ... and in the accumulation kernel (only while 4 lanes per chunk still fit the machine at once)
+    bool acc_pairs = false; // G1 accumulation with dual-issue product pairs at 3 waves/SIMD (k_msm_accumulate<C, 2>): machine-filling sizes only
     // largest window with >= T entries per bucket on average (n * W entries over 2^(c-1) buckets).  T = 32 for one proof at a time:
     // the bucket reduction is latency there and a larger window shortens the accumulation chains.  A batch pays the reduction of
     // every proof's buckets in throughput once its entries fill the machine, and wants fuller buckets: T grows with the entries of
@@ -140,6 +141,10 @@ struct MsmShape {
         quad_acc = all <= (1ull << 17) ? 4 : 1;
         if (const char *e = getenv("ZK_MSM_QUAD")) quad = atoi(e) ? 4 : 1;                                           // tuning aids
         if (const char *e = getenv("ZK_MSM_QUAD_ACC")) quad_acc = atoi(e) ? 4 : 1;
+        // the pairs form wins where the entries fill the machine several times over; below, fewer resident threads only lengthen the chunks
+        // (synchronous proofs, tools/dev_sync_latency.py, plain -> pairs: 2^17 2.38 -> 2.59 ms, 2^18 3.56 -> 3.72, 2^20 10.8 -> 10.4)
+        acc_pairs = all >= (3ull << 21);
+        if (const char *e = getenv("ZK_ACC_PAIRS")) acc_pairs = atoi(e) != 0;
         chunk.seg_min = all <= (1ull << 23) ? MSM_SEG_MIN_SMALL : MSM_SEG_MIN;
         chunk.seg_max = MSM_SEG_MAX;
         if (const char *e = getenv("ZK_SEG_MIN")) { int v = atoi(e); if (v >= 4) chunk.seg_min = (uint32_t)v; }    // tuning aids

@@ -198,13 +198,16 @@ k_sort_fine(const uint2 *__restrict__ pairs, const uint32_t *__restrict__ bin_ba
 // Chunk c starts inside bucket b0 (binary search in off[]); its running sum is flushed as "piece" c + b whenever the
 // entries move on to another bucket b, and at its end: piece numbers grow along the entry list, the pieces of bucket b
 // are off[b] / len + b ... (off[b+1] - 1) / len + b.
+// Q = 2: one lane per chunk like Q = 1, the mixed addition with dual-issue product pairs (Curve::madd_pairs) at the occupancy its
+// registers allow (G1: 3 waves/SIMD instead of 4)
 template <class C, int Q>
-__global__ void __launch_bounds__(64, C::WAVES_PER_SIMD)
+__global__ void __launch_bounds__(64, Q == 2 ? C::WAVES_PER_SIMD_PAIRS : C::WAVES_PER_SIMD)
 k_msm_accumulate(const typename C::Affine *__restrict__ table, const uint32_t *__restrict__ sorted,
                  const uint32_t *__restrict__ off, uint32_t nb, ChunkRule rule,
                  uint32_t remap_src, uint32_t remap_offset, const uint32_t *__restrict__ remap_pos, uint32_t n_dst, uint32_t remap_kbits,
                  typename C::XYZZ *__restrict__ piece) {
-    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x, c = gt / Q, ql = gt % Q;
+    constexpr uint32_t LANES = Q == 4 ? 4 : 1;
+    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x, c = gt / LANES, ql = gt % LANES;
     const uint32_t total = off[nb], seg = rule.len(total);
     if ((uint64_t)c * seg >= total) return;
     const uint32_t begin = c * seg, end = (total - begin < seg) ? total : begin + seg;
@@ -256,7 +259,7 @@ k_msm_accumulate(const typename C::Affine *__restrict__ table, const uint32_t *_
             q = table[idx];
         }
         if (p >> 31) q = C::neg(q);
-        acc = C::template maddQ<Q>(acc, q, ql);                 // an absent entry is the point at infinity: acc unchanged
+        acc = C::template maddV<Q>(acc, q, ql);                 // an absent entry is the point at infinity: acc unchanged
     }
     if (ql == 0) piece[c + b] = acc;
 }
@@ -344,7 +347,7 @@ template <class C>
 int MsmWork<C>::alloc(uint32_t n, uint32_t c, typename C::Affine *shared_table, const MsmShape *sort_like, bool sort_only, uint32_t batch) {
     max_batch = batch ? batch : 1;
     if (sort_like) sh = *sort_like; else sh.set(n ? n : 1, c, max_batch);
-    sh.set_slots(C::WAVES_PER_SIMD);
+    sh.set_slots(sh.acc_pairs && C::WAVES_PER_SIMD_PAIRS != C::WAVES_PER_SIMD ? C::WAVES_PER_SIMD_PAIRS : C::WAVES_PER_SIMD);
     const uint64_t B = max_batch;
     if (sh.max_entries() * B >= (1ull << 31)) return fail_msg(ZK_ERR_ARG, "MSM too large: proofs * n * windows must stay below 2^31 (entry payload = table index | sign)");
     if ((uint64_t)sh.nb * B > (uint64_t)SORT_MAX_CB * SORT_MAX_FB) return fail_msg(ZK_ERR_ARG, "batch too large: proofs * buckets exceeds the sort's 2^20 buckets");
@@ -452,6 +455,9 @@ int MsmWork<C>::enqueue_reduce(const SortView &v, hipStream_t st, hipStream_t st
     ZK_HIP(hipEventRecord(ev_acc0, st));
     if (sh.quad_acc == 4)
         ZK_LAUNCH((k_msm_accumulate<C, 4>), zk_div_up(max_seg * 4, 64), 64, st, (const typename C::Affine *)table, v.sorted, v.off,
+                  nb, sh.chunk, v.remap_src, v.remap_offset, v.remap_pos, table_n, v.remap_kbits, pieces);
+    else if (sh.acc_pairs && C::WAVES_PER_SIMD_PAIRS != C::WAVES_PER_SIMD)
+        ZK_LAUNCH((k_msm_accumulate<C, 2>), zk_div_up(max_seg, 64), 64, st, (const typename C::Affine *)table, v.sorted, v.off,
                   nb, sh.chunk, v.remap_src, v.remap_offset, v.remap_pos, table_n, v.remap_kbits, pieces);
     else
         ZK_LAUNCH((k_msm_accumulate<C, 1>), zk_div_up(max_seg, 64), 64, st, (const typename C::Affine *)table, v.sorted, v.off,

@@ -721,8 +721,15 @@ static int ctx_build(zk_ctx *c, const zk_pk *pk, const zk_csr *A, const zk_csr *
     // stream priorities, in the order main, accumulate, A-tail, B-tail, L-tail: h(igh) / n(ormal) / l(ow).  Measured at 2^20 with
     // three proofs in flight (profiles/r02_stream_priorities.txt): the accumulations and the A- / L-tails low, the rest high is
     // the best of the combinations tried; every tail high costs 12 % (their few, register-heavy waves push accumulation waves out).
+    // zk_config.schedule = ZK_SCHED_LATENCY (a context that proves one synchronous proof at a time: ethsnarks::prove): every stream at the
+    // same priority for circuits past the small-proof schedule.  How the runtime spreads a context's streams over its hardware queues (a
+    // pool of GPU_MAX_HW_QUEUES = 4 per priority) decides how fast the proof's ~25 short kernels get dispatched beside its four long ones:
+    // synchronous zk_prove, mixed -> all high: 2^16 1.99 -> 1.62 ms, 2^18 3.68 -> 3.38, 2^20 10.52 -> 10.22; the small circuits (Merkle-29
+    // 1.18 -> 1.39, 2^14 1.23 -> 1.34) and pipelined contexts (2^18: 306 -> 275 proofs/s) want the mixed priorities
+    // (tools/dev_queue_map.py, tools/dev_sync_latency.py; profiles/r03_queue_mapping.txt).
+    const bool latency_sched = c->cfg.schedule == ZK_SCHED_LATENCY && (uint64_t)c->mH.sh.max_entries() * c->max_batch >= (3ull << 18);
     const char *pr = getenv("ZK_PRIOS");                              // tuning aid
-    if (!pr || strlen(pr) != 5) pr = "hllhl";
+    if (!pr || strlen(pr) != 5) pr = latency_sched ? "hhhhh" : "hllhl";
     auto prio = [&](char ch) { return ch == 'h' ? prio_hi : ch == 'l' ? prio_lo : (prio_hi + prio_lo) / 2; };
     for (int i = 0; i < 5; i++) c->stream_prio[i] = prio(pr[i]);
     ZK_TRY(stream_take(&c->s_main, c->device, ROLE_MAIN, c->stream_prio[ROLE_MAIN]));

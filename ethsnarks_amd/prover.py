@@ -73,6 +73,7 @@ EXPORTS = [
 
 _lib = None
 _lib_path_loaded = None
+_legacy_abi = False
 
 
 def load_library(path=None):
@@ -93,9 +94,15 @@ def load_library(path=None):
     L.zk_ctx_partials_device.restype = C.c_void_p
     L.zk_chain_device.restype = C.c_void_p
     L.zk_h_device.restype = C.c_void_p
-    L.zk_abi_version.restype = C.c_uint32
-    if L.zk_abi_version() != ABI_VERSION:                # struct layouts of this binding (ZkConfig ...) are those of include/zkhip.h ZK_ABI_VERSION
-        raise ImportError("%s has ABI version %d, this binding was written for %d" % (path, L.zk_abi_version(), ABI_VERSION))
+    global _legacy_abi
+    try:
+        L.zk_abi_version.restype = C.c_uint32
+        have = L.zk_abi_version()
+    except AttributeError:
+        have = 2                                           # rounds 1-2: no zk_abi_version; zk_config had the same six members in round 2
+    _legacy_abi = have != ABI_VERSION
+    if _legacy_abi and not (have == 2 and os.environ.get("ZK_LIB_ALLOW_OLD_ABI") == "1"):   # (dev aid: same-box A/B against a round-2 build)
+        raise ImportError("%s has ABI version %d, this binding was written for %d" % (path, have, ABI_VERSION))   # struct layouts are those of include/zkhip.h
     _lib, _lib_path_loaded = L, path
     return L
 
@@ -308,17 +315,21 @@ def get_domain_size(r1cs):
 class ProverContext:
     """ProverContext<ppT> (hpp:279-291) + get_domain: bases and CSR resident in HBM, scratch owned."""
 
-    def __init__(self, pk, r1cs, multi_exp_c=0, device=0, shard_rank=0, shard_count=1, max_batch=1, one_stream=False):
-        """one_stream: zk_config.schedule = ZK_SCHED_ONE_STREAM (many small proofs in many contexts)"""
+    def __init__(self, pk, r1cs, multi_exp_c=0, device=0, shard_rank=0, shard_count=1, max_batch=1, one_stream=False, latency=False):
+        """one_stream: zk_config.schedule = ZK_SCHED_ONE_STREAM (many small proofs in many contexts); latency: ZK_SCHED_LATENCY (a context
+        that proves one synchronous proof at a time, what ethsnarks::prove creates)"""
         lib = load_library(_lib_path_loaded)
         self.r1cs = r1cs
         self.max_batch = max_batch
         self._keep = []
         a, b, c = _csr_structs(r1cs, self._keep)
-        cfg = ZkConfig(multi_exp_c, device, shard_rank, shard_count, max_batch, 1 if one_stream else 0)
+        cfg = ZkConfig(multi_exp_c, device, shard_rank, shard_count, max_batch, 1 if one_stream else 2 if latency else 0)
         h = C.c_void_p()
-        _check(lib.zk_ctx_create_sized(pk._h, C.byref(a), C.byref(b), C.byref(c), C.c_uint32(r1cs.nC), C.c_uint32(r1cs.nIn),
-                                       C.c_uint32(r1cs.V), C.byref(cfg), C.c_size_t(C.sizeof(cfg)), C.byref(h)))
+        if _legacy_abi:
+            _check(lib.zk_ctx_create(pk._h, C.byref(a), C.byref(b), C.byref(c), C.c_uint32(r1cs.nC), C.c_uint32(r1cs.nIn), C.c_uint32(r1cs.V), C.byref(cfg), C.byref(h)))
+        else:
+            _check(lib.zk_ctx_create_sized(pk._h, C.byref(a), C.byref(b), C.byref(c), C.c_uint32(r1cs.nC), C.c_uint32(r1cs.nIn),
+                                           C.c_uint32(r1cs.V), C.byref(cfg), C.c_size_t(C.sizeof(cfg)), C.byref(h)))
         self._h = h
         self._keep = []     # the context copied everything it needs
         self.shard_count = shard_count

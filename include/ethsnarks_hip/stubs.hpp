@@ -224,7 +224,7 @@ inline void ensure_context(ProverContextT &context, const ProtoboardT &pb) {
     if (context.ctx) return;
     const FlatSystem f(context.constraint_system ? *context.constraint_system : pb.constraint_system);
     const zk_csr a = f.a(), b = f.b(), c = f.c();
-    zk_config cfg{context.config.multi_exp_c, hip_device(), 0, 1, 1, ZK_SCHED_OVERLAP};
+    zk_config cfg{context.config.multi_exp_c, hip_device(), 0, 1, 1, ZK_SCHED_LATENCY};      // prove() is one synchronous proof at a time
     zk_ctx *h = nullptr;
     zk_check(zk_ctx_create_sized(context.provingKey.get(), &a, &b, &c, f.nC, f.nIn, f.V, &cfg, sizeof(cfg), &h));   // the size this translation unit was compiled with
     context.ctx.reset(h, zk_ctx_destroy);

@@ -86,10 +86,14 @@ typedef struct {
     uint32_t schedule;         /* ZK_SCHED_OVERLAP (0): the proof's sorts, accumulations and reduction tails on five streams --
                                 * lowest latency of one proof, what large circuits want; ZK_SCHED_ONE_STREAM (1): every launch on one
                                 * stream -- for many small proofs in many contexts (a hardware queue runs its dispatches in order, so
-                                * fewer streams per context leave more queues to other contexts: profiles/r02_small_circuit_concurrency.txt) */
+                                * fewer streams per context leave more queues to other contexts: profiles/r02_small_circuit_concurrency.txt);
+                                * ZK_SCHED_LATENCY (2): ZK_SCHED_OVERLAP for a context that proves ONE synchronous proof at a time (zk_prove =
+                                * ethsnarks::prove): its streams share one priority, which shortens a lone proof of 2^16 constraints and more
+                                * by 3-19 % and costs pipelined contexts 10 % (profiles/r03_queue_mapping.txt) */
 } zk_config;
 #define ZK_SCHED_OVERLAP 0
 #define ZK_SCHED_ONE_STREAM 1
+#define ZK_SCHED_LATENCY 2
 
 /* canonical (non-Montgomery) affine coordinates; *_inf != 0 => point at infinity, printed as (0, 1) */
 typedef struct {

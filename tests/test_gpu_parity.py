@@ -79,13 +79,14 @@ def test_msm_exceptional_cases(hip, oracle):
     assert (hip.msm(bases, F.fr_to_mont([3, 3, 0, 0]), c=3) == 0).all()
 
 
-@pytest.mark.parametrize("quad,quad_acc", [("1", "1"), ("1", "0"), ("0", "0")], ids=["quad", "quad-tails", "one-lane"])
+@pytest.mark.parametrize("quad,quad_acc,pairs", [("1", "1", "0"), ("1", "0", "0"), ("0", "0", "0"), ("0", "0", "1")], ids=["quad", "quad-tails", "one-lane", "one-lane-pairs"])
 @pytest.mark.parametrize("g2", [False, True], ids=["G1", "G2"])
-def test_msm_lane_layouts_and_segment_level_exceptions(hip, oracle, monkeypatch, g2, quad, quad_acc):
+def test_msm_lane_layouts_and_segment_level_exceptions(hip, oracle, monkeypatch, g2, quad, quad_acc, pairs):
     """Both lane layouts of the accumulation / reduction kernels (four cooperating lanes per logical thread for small
     MSMs, one for large ones) on inputs whose SEGMENT sums collide: 16 copies of P under one scalar (8-entry segments ->
     8P + 8P, the doubling branch of the XYZZ addition), then 8 x P and 8 x -P (8P + -8P = infinity), plus ordinary data."""
     monkeypatch.setenv("ZK_MSM_QUAD", quad); monkeypatch.setenv("ZK_MSM_QUAD_ACC", quad_acc)
+    monkeypatch.setenv("ZK_ACC_PAIRS", pairs)              # the mixed addition with dual-issue product pairs (what machine-filling G1 sizes use)
     pts = oracle.batch_mul(F.fr_to_mont([5, 9]), g2=g2)
     neg = pts[1].copy()
     k = 8 if g2 else 4                                     # limbs (u64) of one coordinate

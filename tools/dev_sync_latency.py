@@ -11,7 +11,7 @@ for name in sys.argv[1:] or ["merkle29", "mimc11", "14", "16"]:
     else: r, w = R.synthetic_chain((1 << int(name)) - 2, 1)
     wm = F.fr_to_mont(w)
     pk, vk = P.keygen(r, seed=3)
-    ctx = P.ProverContext(pk, r)
+    ctx = P.ProverContext(pk, r, latency=os.environ.get('ZK_NO_LATENCY_SCHED') != '1')       # what ethsnarks::prove's context is created with
     for _ in range(5): ctx.prove_struct(wm)
     ts = []
     for _ in range(60):

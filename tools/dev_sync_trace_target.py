@@ -12,7 +12,7 @@ elif name == "mimc11": r, w, _ = G.mimc_preimage_circuit(11)
 else: r, w = R.synthetic_chain((1 << int(name)) - 2, 1)
 wm = F.fr_to_mont(w)
 pk, vk = P.keygen(r, seed=3)
-ctx = P.ProverContext(pk, r)
+ctx = P.ProverContext(pk, r, latency=os.environ.get('ZK_NO_LATENCY_SCHED') != '1')       # what ethsnarks::prove's context is created with
 ts = []
 for _ in range(n):
     t = time.perf_counter(); ctx.prove_struct(wm); ts.append(time.perf_counter() - t)
