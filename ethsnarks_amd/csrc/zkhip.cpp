@@ -1363,44 +1363,101 @@ extern "C" int zk_keygen(const zk_csr *A, const zk_csr *B, const zk_csr *C, uint
 // A plan (zk_wplan) is that program compiled once; zk_wplan_solve runs it for k witnesses at a time, one thread per witness
 // (the k threads walk the same constraints in lock step: no divergence), directly in the buffer zk_prove_batch_submit_resident
 // then proves from -- the witnesses never visit the host.  Constraints that introduce nothing are checked instead.
+// Round 3: the program is a TAPE.  The first version walked the three CSR matrices (row pointers -> column / coefficient -> witness
+// value: three dependent global-load round trips per constraint, 3 us each, 62-72 ms for the 21 345 constraints of the depth-29 Merkle
+// circuit whatever k).  The tape is a sequence of fixed-size records of WP_WORDS 32-bit words that the wave reads with SCALAR loads (every
+// lane = witness executes the same record; a record's address does not depend on data, so the next one is in flight while this one is
+// evaluated):
+//     word 0   nA | nB << 8 | nC << 16 | has_inverse << 24 | partial << 25     (terms held by THIS record: nA, nB <= 3, nC <= 2)
+//     word 1   target variable (0xffffffff: nothing introduced, check)          word 2   index of 1 / C_{j,target} in the coefficient table
+//     word 3   cache slot the result goes to
+//     words 4..9 the A terms, 10..15 the B terms, 16..19 the C terms, two words each:
+//     term.0   column | kind << 28 | fill << 30     kind 0: + w, 1: - w, 2: + coef w (a product), 3: + coef (a term on the constant ONE)
+//     term.1   coefficient index | (slot + 1) << 24  slot + 1 = 0: load w[column] from memory (fill: and keep it in the slot given), else
+//                                                    the value is in that slot of the cache
+// A constraint with longer linear combinations spans several records (partial = 1 on all but the last: the sums carry over).
+// The cache is WP_SLOTS witness values per lane in LDS, managed at COMPILE time (least recently used): the kernel indexes it with the
+// slot number the tape names -- a dynamically indexed register file -- so a chain of constraints (MiMC: every constraint reads the one or
+// two before it, every round the key) never waits for its own store to come back from memory; what remains per constraint is about one
+// Montgomery product and one or two additions of a lone wave, ~410 VALU instructions (SQ counters).
 namespace {
-__global__ void k_witness_solve(const uint32_t *__restrict__ a_ptr, const uint32_t *__restrict__ a_col, const fe *__restrict__ a_cf,
-                                const uint32_t *__restrict__ b_ptr, const uint32_t *__restrict__ b_col, const fe *__restrict__ b_cf,
-                                const uint32_t *__restrict__ c_ptr, const uint32_t *__restrict__ c_col, const fe *__restrict__ c_cf,
-                                const uint32_t *__restrict__ target, const fe *__restrict__ inv, uint32_t nC,
-                                fe *__restrict__ w, uint32_t stride, uint32_t k, uint32_t *__restrict__ violations) {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= k) return;
-    fe *x = w + (size_t)p * stride;
+constexpr uint32_t WP_SLOTS = 32, WP_WORDS = 20, WP_A = 4, WP_B = 10, WP_C = 16, WP_NA = 3, WP_NB = 3, WP_NC = 2;
+__global__ void __launch_bounds__(64)
+k_witness_tape(const uint32_t *__restrict__ tape, uint32_t n_records, const fe *__restrict__ coefs,
+               fe *__restrict__ w, uint32_t stride, uint32_t k, uint32_t *__restrict__ violations) {
+    __shared__ uint32_t cache[WP_SLOTS][8][64];                  // [slot][limb][lane]: conflict-free, 64 KiB
+    const uint32_t lane = threadIdx.x, p = blockIdx.x * blockDim.x + lane;
+    const bool live = p < k;
+    fe *x = w + (size_t)(live ? p : 0) * stride;                 // (idle lanes of the last wave shadow witness 0 and store nothing)
+    fe lcA = Fr::zero(), lcB = lcA, lcC = lcA;
+    bool eA = true, eB = true, eC = true;                        // (uniform) the sums are still empty: the first term is moved, not added
     uint32_t bad = 0;
-    for (uint32_t j = 0; j < nC; j++) {
-        fe a = Fr::zero(), b = Fr::zero(), s = Fr::zero();
-        for (uint32_t e = a_ptr[j]; e < a_ptr[j + 1]; e++) a = Fr::add(a, spmv_term(a_cf[e], x[a_col[e]]));
-        for (uint32_t e = b_ptr[j]; e < b_ptr[j + 1]; e++) b = Fr::add(b, spmv_term(b_cf[e], x[b_col[e]]));
-        const uint32_t t = target[j];
-        for (uint32_t e = c_ptr[j]; e < c_ptr[j + 1]; e++) if (c_col[e] != t) s = Fr::add(s, spmv_term(c_cf[e], x[c_col[e]]));
-        fe v = Fr::sub(Fr::mul(a, b), s);
-        if (t == 0xffffffffu) { bad += !Fr::is_zero(v); continue; }
-        const fe iv = inv[j];
-        x[t] = fr_is_one(iv) ? v : Fr::mul(v, iv);
+    auto cache_get = [&](uint32_t slot) { fe v;
+#pragma unroll
+        for (int l = 0; l < 8; l++) v.l[l] = cache[slot][l][lane];
+        return v; };
+    auto cache_put = [&](uint32_t slot, const fe &v) {
+#pragma unroll
+        for (int l = 0; l < 8; l++) cache[slot][l][lane] = v.l[l]; };
+    // general coefficients (kind 2: a product per term) and inverses are rare in gadget circuits (none in the MiMC / Merkle ones): one
+    // shared, out-of-line product site keeps the straight-line code of the eight term slots small
+    fe gen_v = lcA; uint32_t gen_c = 0;
+    auto GENERAL = [&]() __attribute__((noinline)) { gen_v = Fr::mul(coefs[gen_c], gen_v); };
+    // (requesting all operands of a record first and folding them afterwards -- two sweeps -- was measured: 39 ms against 35.6)
+#define ZK_WP_TERM(ACC, EMPTY, W0, W1) { \
+        const uint32_t t0_ = (W0), t1_ = (W1), kind_ = (t0_ >> 28) & 3u, slot1_ = (t1_ >> 24) & 0x3fu; \
+        fe v_; \
+        if (kind_ == 3) v_ = coefs[t1_ & 0xffffffu]; \
+        else if (slot1_ && !((t0_ >> 30) & 1u)) v_ = cache_get(slot1_ - 1); \
+        else { v_ = x[t0_ & 0x0fffffffu]; if (slot1_) cache_put(slot1_ - 1, v_); } \
+        if (kind_ == 2) { gen_v = v_; gen_c = t1_ & 0xffffffu; GENERAL(); v_ = gen_v; } \
+        if (EMPTY) { ACC = kind_ == 1 ? Fr::neg(v_) : v_; EMPTY = false; } \
+        else ACC = kind_ == 1 ? Fr::sub(ACC, v_) : Fr::add(ACC, v_); }
+    uint32_t nx[WP_WORDS];                                       // the NEXT record, requested one iteration ahead (scalar registers)
+#pragma unroll
+    for (uint32_t i = 0; i < WP_WORDS; i++) nx[i] = tape[i];
+    for (uint32_t j = 0; j < n_records; j++) {
+        uint32_t rec[WP_WORDS];
+#pragma unroll
+        for (uint32_t i = 0; i < WP_WORDS; i++) rec[i] = nx[i];
+        const uint32_t *nrec = tape + (size_t)(j + 1) * WP_WORDS;     // (the tape ends in empty records: reading ahead is safe)
+#pragma unroll
+        for (uint32_t i = 0; i < WP_WORDS; i++) nx[i] = nrec[i];
+        const uint32_t head = rec[0], target = rec[1], inv_idx = rec[2], out_slot = rec[3];
+        const uint32_t nA = head & 0xffu, nB = (head >> 8) & 0xffu, nC = (head >> 16) & 0xffu;
+        if (nA > 0) ZK_WP_TERM(lcA, eA, rec[WP_A + 0], rec[WP_A + 1])
+        if (nA > 1) ZK_WP_TERM(lcA, eA, rec[WP_A + 2], rec[WP_A + 3])
+        if (nA > 2) ZK_WP_TERM(lcA, eA, rec[WP_A + 4], rec[WP_A + 5])
+        if (nB > 0) ZK_WP_TERM(lcB, eB, rec[WP_B + 0], rec[WP_B + 1])
+        if (nB > 1) ZK_WP_TERM(lcB, eB, rec[WP_B + 2], rec[WP_B + 3])
+        if (nB > 2) ZK_WP_TERM(lcB, eB, rec[WP_B + 4], rec[WP_B + 5])
+        if (nC > 0) ZK_WP_TERM(lcC, eC, rec[WP_C + 0], rec[WP_C + 1])
+        if (nC > 1) ZK_WP_TERM(lcC, eC, rec[WP_C + 2], rec[WP_C + 3])
+        if ((head >> 25) & 1u) continue;                         // partial record: the constraint's sums go on in the next one
+        fe v = (eA || eB) ? Fr::zero() : Fr::mul(lcA, lcB);      // an empty sum is 0
+        if (!eC) v = Fr::sub(v, lcC);
+        eA = eB = eC = true;
+        if (target == 0xffffffffu) { bad += live && !Fr::is_zero(v); continue; }
+        if ((head >> 24) & 1u) { gen_v = v; gen_c = inv_idx; GENERAL(); v = gen_v; }
+        if (live) x[target] = v;
+        cache_put(out_slot, v);
     }
+#undef ZK_WP_TERM
     if (bad) atomicAdd(violations, bad);
 }
 }  // namespace
 
 struct zk_wplan {
     int device = 0;
-    uint32_t nC = 0, V = 0;
-    DevCsr A, B, C;
-    uint32_t *d_target = nullptr, *d_viol = nullptr;
-    fe *d_inv = nullptr;
+    uint32_t nC = 0, V = 0, n_records = 0;
+    uint32_t *d_tape = nullptr, *d_viol = nullptr;
+    fe *d_coefs = nullptr;
     hipStream_t st = nullptr;
     ~zk_wplan() {
         hipSetDevice(device);
-        A.release(); B.release(); C.release();
-        if (d_target) hipFree(d_target);
+        if (d_tape) hipFree(d_tape);
         if (d_viol) hipFree(d_viol);
-        if (d_inv) hipFree(d_inv);
+        if (d_coefs) hipFree(d_coefs);
         if (st) hipStreamDestroy(st);
     }
 };
@@ -1409,11 +1466,23 @@ extern "C" int zk_wplan_create(const zk_csr *A, const zk_csr *B, const zk_csr *C
                                const uint8_t *known, int device, zk_wplan **out) {
     if (!A || !B || !C || !known || !out) return fail(ZK_ERR_ARG, "null argument");
     if (A->n_rows != nC || B->n_rows != nC || C->n_rows != nC) return fail(ZK_ERR_ARG, "CSR row counts must equal nC");
+    if (V >= (1u << 28)) return fail(ZK_ERR_ARG, "witness plan: more than 2^28 variables");
     ZK_TRY(use_device(device));
     std::vector<uint8_t> have(known, known + (size_t)V + 1);
     have[0] = 1;                                                     // the constant ONE
-    std::vector<uint32_t> target(nC, 0xffffffffu);
-    std::vector<fe> inv(nC, Fr::one());
+    std::vector<uint32_t> tape;
+    std::vector<fe> coefs;                                           // distinct coefficients (and inverses), Montgomery
+    auto coef_index = [&](const fe &c) -> uint32_t {                 // (linear search from the back: gadget circuits reuse few values)
+        for (size_t i = coefs.size(); i-- > 0 && coefs.size() - i <= 64;) if (Fr::eq(coefs[i], c)) return (uint32_t)i;
+        coefs.push_back(c); return (uint32_t)coefs.size() - 1;
+    };
+    const fe one = Fr::one(), minus_one = Fr::neg(one);
+    // the kernel's per-lane cache of WP_SLOTS witness values, simulated here: which variable sits in which slot, least recently used out
+    uint32_t slot_var[WP_SLOTS]; uint64_t slot_used[WP_SLOTS]; uint64_t tick = 0;
+    for (uint32_t i = 0; i < WP_SLOTS; i++) { slot_var[i] = 0xffffffffu; slot_used[i] = 0; }
+    auto cache_find = [&](uint32_t v) -> int { for (uint32_t i = 0; i < WP_SLOTS; i++) if (slot_var[i] == v) { slot_used[i] = ++tick; return (int)i; } return -1; };
+    auto cache_alloc = [&](uint32_t v) -> uint32_t { uint32_t best = 0; for (uint32_t i = 1; i < WP_SLOTS; i++) if (slot_used[i] < slot_used[best]) best = i;
+                                                     slot_var[best] = v; slot_used[best] = ++tick; return best; };
     char msg[200];
     for (uint32_t j = 0; j < nC; j++) {
         const zk_csr *M[2] = {A, B};
@@ -1422,27 +1491,72 @@ extern "C" int zk_wplan_create(const zk_csr *A, const zk_csr *B, const zk_csr *C
                 if (M[q]->col[e] > V) return fail(ZK_ERR_ARG, "CSR column index exceeds the number of variables");
                 if (!have[M[q]->col[e]]) { snprintf(msg, sizeof(msg), "constraint %u reads variable %u in %c before anything defines it: not in solved order", j, M[q]->col[e], q ? 'B' : 'A'); return fail(ZK_ERR_ARG, msg); }
             }
+        uint32_t target = 0xffffffffu; fe tcoef = one;
         for (uint32_t e = C->row_ptr[j]; e < C->row_ptr[j + 1]; e++) {
             const uint32_t v = C->col[e];
             if (v > V) return fail(ZK_ERR_ARG, "CSR column index exceeds the number of variables");
             if (have[v]) continue;
-            if (target[j] != 0xffffffffu) { snprintf(msg, sizeof(msg), "constraint %u introduces two new variables (%u and %u)", j, target[j], v); return fail(ZK_ERR_ARG, msg); }
+            if (target != 0xffffffffu) { snprintf(msg, sizeof(msg), "constraint %u introduces two new variables (%u and %u)", j, target, v); return fail(ZK_ERR_ARG, msg); }
             fe cf; memcpy(cf.l, C->coeff + 4 * (size_t)e, 32);
             if (Fr::is_zero(cf)) return fail(ZK_ERR_ARG, "zero coefficient on the variable a constraint introduces");
-            target[j] = v;
-            if (!fr_is_one(cf)) inv[j] = Fr::inv(cf);
+            target = v; tcoef = cf;
         }
-        if (target[j] != 0xffffffffu) have[target[j]] = 1;
+        const bool has_inv = target != 0xffffffffu && !Fr::eq(tcoef, one);
+        const uint32_t inv_idx = has_inv ? coef_index(Fr::inv(tcoef)) : 0u;
+        // the constraint's terms, encoded, per linear combination
+        std::vector<uint32_t> terms[3];
+        const zk_csr *Ms[3] = {A, B, C};
+        for (int q = 0; q < 3; q++)
+            for (uint32_t e = Ms[q]->row_ptr[j]; e < Ms[q]->row_ptr[j + 1]; e++) {
+                const uint32_t col = Ms[q]->col[e];
+                if (q == 2 && col == target) continue;
+                fe cf; memcpy(cf.l, Ms[q]->coeff + 4 * (size_t)e, 32);
+                if (Fr::is_zero(cf)) continue;
+                uint32_t kind, ci = 0, slot1 = 0, fill = 0;
+                if (col == 0) { kind = 3; ci = coef_index(cf); }                    // coef * ONE: the coefficient itself
+                else {
+                    if (Fr::eq(cf, one)) kind = 0;
+                    else if (Fr::eq(cf, minus_one)) kind = 1;
+                    else { kind = 2; ci = coef_index(cf); }
+                    const int hit = cache_find(col);
+                    if (hit >= 0) slot1 = (uint32_t)hit + 1;
+                    else { slot1 = cache_alloc(col) + 1; fill = 1; }                // from memory this once, then from the cache
+                }
+                if (ci >= (1u << 24)) return fail(ZK_ERR_ARG, "witness plan: more than 2^24 distinct coefficients");
+                terms[q].push_back(col | kind << 28 | fill << 30);
+                terms[q].push_back(ci | slot1 << 24);
+            }
+        // records of at most WP_NA / WP_NB / WP_NC terms; all but the last are partial
+        size_t done[3] = {0, 0, 0};
+        for (;;) {
+            uint32_t rec[WP_WORDS] = {0};
+            const uint32_t cap[3] = {WP_NA, WP_NB, WP_NC}, at[3] = {WP_A, WP_B, WP_C};
+            uint32_t n[3];
+            bool more = false;
+            for (int q = 0; q < 3; q++) {
+                const size_t left = terms[q].size() / 2 - done[q];
+                n[q] = (uint32_t)(left < cap[q] ? left : cap[q]);
+                for (uint32_t t = 0; t < 2 * n[q]; t++) rec[at[q] + t] = terms[q][2 * done[q] + t];
+                done[q] += n[q];
+                more |= done[q] < terms[q].size() / 2;
+            }
+            rec[0] = n[0] | n[1] << 8 | n[2] << 16 | (has_inv ? 1u << 24 : 0u) | (more ? 1u << 25 : 0u);
+            rec[1] = target; rec[2] = inv_idx;
+            if (!more && target != 0xffffffffu) rec[3] = cache_alloc(target);       // where the result is kept
+            tape.insert(tape.end(), rec, rec + WP_WORDS);
+            if (!more) break;
+        }
+        if (target != 0xffffffffu) have[target] = 1;
     }
     for (uint32_t v = 0; v <= V; v++) if (!have[v]) { snprintf(msg, sizeof(msg), "variable %u is neither supplied nor defined by a constraint", v); return fail(ZK_ERR_ARG, msg); }
+    const uint32_t n_records = (uint32_t)(tape.size() / WP_WORDS);
+    tape.insert(tape.end(), 3 * WP_WORDS, 0u);                       // the read-ahead past the last record finds empty records
+    if (coefs.empty()) coefs.push_back(one);
     zk_wplan *p = new (std::nothrow) zk_wplan();
     if (!p) return ZK_ERR_NOMEM;
-    p->device = device; p->nC = nC; p->V = V;
-    int rc = p->A.upload(A, V, 1);
-    if (rc == ZK_OK) rc = p->B.upload(B, V, 1);
-    if (rc == ZK_OK) rc = p->C.upload(C, V, 1);
-    if (rc == ZK_OK) rc = dev_upload(&p->d_target, target.data(), target.size());
-    if (rc == ZK_OK) rc = dev_upload(&p->d_inv, inv.data(), inv.size());
+    p->device = device; p->nC = nC; p->V = V; p->n_records = n_records;
+    int rc = dev_upload(&p->d_tape, tape.data(), tape.size());
+    if (rc == ZK_OK) rc = dev_upload(&p->d_coefs, coefs.data(), coefs.size());
     if (rc == ZK_OK && hipMalloc(&p->d_viol, 4) != hipSuccess) rc = ZK_ERR_NOMEM;
     if (rc == ZK_OK && hipStreamCreateWithFlags(&p->st, hipStreamNonBlocking) != hipSuccess) rc = ZK_ERR_HIP;
     if (rc != ZK_OK) { delete p; return rc; }
@@ -1456,10 +1570,7 @@ extern "C" int zk_wplan_solve(zk_wplan *p, void *d_w, uint32_t k, uint32_t *viol
     if (!p || !d_w || !k) return fail(ZK_ERR_ARG, "bad argument");
     ZK_TRY(use_device(p->device));
     ZK_HIP(hipMemsetAsync(p->d_viol, 0, 4, p->st));
-    ZK_LAUNCH(k_witness_solve, zk_div_up(k, 64), 64, p->st, (const uint32_t *)p->A.row_ptr, (const uint32_t *)p->A.col, (const fe *)p->A.coeff,
-              (const uint32_t *)p->B.row_ptr, (const uint32_t *)p->B.col, (const fe *)p->B.coeff,
-              (const uint32_t *)p->C.row_ptr, (const uint32_t *)p->C.col, (const fe *)p->C.coeff,
-              (const uint32_t *)p->d_target, (const fe *)p->d_inv, p->nC, (fe *)d_w, p->V + 1, k, p->d_viol);
+    ZK_LAUNCH(k_witness_tape, zk_div_up(k, 64), 64, p->st, (const uint32_t *)p->d_tape, p->n_records, (const fe *)p->d_coefs, (fe *)d_w, p->V + 1, k, p->d_viol);
     uint32_t v = 0;
     ZK_HIP(hipMemcpyAsync(&v, p->d_viol, 4, hipMemcpyDeviceToHost, p->st));
     ZK_HIP(hipStreamSynchronize(p->st));
