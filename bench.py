@@ -296,7 +296,7 @@ def main():
             short = max(3, min(args.steps, 10))
             modes = {}
             for other in WITNESS_MODES:                             # the other ways to hand the witness over, legs as long as the headline leg
-                if other == args.witness or shard:
+                if other == args.witness or shard or world > 1:     # (a one-GPU property: the scaling runs spend their time on the sharded legs)
                     continue
                 try:
                     h2 = run_leg(pk, r1cs, wm, shard, args.steps, args.warmup, other)
