@@ -79,7 +79,7 @@ def main():
     ap.add_argument("--batch-identical", action="store_true", help="--batch k: k copies of ONE witness instead of k different ones (shows what identical digits / gather addresses are worth)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary legs (host-witness rate, sharded legs, kernel sum)")
-    ap.add_argument("--cpu-1t-logm", type=int, default=16, help="size of the one-thread CPU sample (a full 2^20 proof takes a minute on one core)")
+    ap.add_argument("--cpu-1t-logm", type=int, default=18, help="size of the one-thread CPU sample (a full 2^20 proof takes more than a minute on one core; 2^18: ~17 s)")
     ap.add_argument("--shard-logm", type=int, default=22, help="size of the config-5 sharded leg at N > 1")
     ap.add_argument("--extras-timeout", type=int, default=420, help="N > 1: seconds the secondary legs may take before the headline line is printed without them")
     args = ap.parse_args()

@@ -109,3 +109,19 @@ def test_unknown_raw_codec_is_rejected(tmp_path):
         prover.load_proving_key(str(tmp_path / "pk.raw"), codec=77)
     assert e.value.code == 1
     prover._lib = None; prover._lib_path_loaded = None
+
+
+@pytest.mark.skipif(not os.path.exists(LIB), reason="libzkhip.so not built (run __graft_entry__.build())")
+def test_abi_version_and_sized_config():
+    """ZK_ABI_VERSION of the header == zk_abi_version() of the library == the binding's; zk_ctx_create_sized takes the caller's
+    sizeof(zk_config) (argument checks run before any device work, so this needs no GPU: a null key is ZK_ERR_ARG either way)"""
+    import re
+    from ethsnarks_amd import prover
+    L = C.CDLL(LIB)
+    L.zk_abi_version.restype = C.c_uint32
+    header = open(os.path.join(ROOT, "include", "zkhip.h")).read()
+    assert int(re.search(r"#define ZK_ABI_VERSION (\d+)", header).group(1)) == L.zk_abi_version() == prover.ABI_VERSION
+    assert C.sizeof(prover.ZkConfig) == 24                     # the layout ABI version 3 names
+    cfg = prover.ZkConfig(0, 0, 0, 1, 1, 0)
+    out = C.c_void_p()
+    assert L.zk_ctx_create_sized(None, None, None, None, 0, 0, 0, C.byref(cfg), C.c_size_t(16), C.byref(out)) == 1   # ZK_ERR_ARG (null key), not a crash

@@ -101,6 +101,19 @@ def test_adapter_prover_context_call_sequence(exe, tmp_path):
 
 
 @pytest.mark.gpu
+def test_adapter_phase_report_is_opt_in(exe, tmp_path):
+    """The reference's prover reports its phases through libff::enter_block / leave_block (tcc:454-544).  The adapter's prove() prints
+    the same block names with the GPU time of each phase only when asked (ZK_PROFILING_INFO=1 / inhibit_profiling_info() = false);
+    by default a caller's stdout is what the test above sees ("VERIFIED" alone)."""
+    args = [exe, "context", str(tmp_path / "pk.raw"), str(tmp_path / "vk.json")]
+    p = subprocess.run(args, capture_output=True, text=True, env=dict(os.environ, ZK_PROFILING_INFO="1"))
+    assert p.returncode == 0 and p.stdout.strip().endswith("VERIFIED"), p.stdout + p.stderr
+    for name in ("Call to r1cs_gg_ppzksnark_zok_prover", "Compute the polynomial H", "Compute the proof", "Compute evaluation to A-query",
+                 "Compute evaluation to B-query", "Compute evaluation to H-query", "Compute evaluation to L-query", "* G1 elements in proof: 2", "* G2 elements in proof: 1"):
+        assert name in p.stdout, name
+
+
+@pytest.mark.gpu
 def test_adapter_cli_helpers(exe, tmp_path):
     """stub_main_genkeys<GadgetT> -> stub_main_prove<GadgetT> -> stub_main_verify with the reference's argv shapes and exit codes
     (src/stubs.hpp:36-55, src/stubs.cpp:90-132)"""
