@@ -272,15 +272,32 @@ k_spmv_long_chunks(const uint32_t *__restrict__ chunk_begin, const uint32_t *__r
     if (threadIdx.x == 0) partial[blockIdx.x] = acc;
 }
 
-// thread per long row: sum its chunk partials (chunks of a row are consecutive)
-__global__ void k_spmv_long_finish(const uint32_t *__restrict__ long_row, const uint32_t *__restrict__ long_first_chunk,
-                                   const fe *__restrict__ partial, fe *__restrict__ out, uint32_t n_long, uint32_t n_chunks, uint32_t out_stride) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+// workgroup per long row: sum its chunk partials (chunks of a row are consecutive) -- strided partial sums, then an LDS tree.
+// (One THREAD per row summed 256 partials through 256 dependent loads and additions: 53 us per launch at 2^20.)
+__global__ void __launch_bounds__(256)
+k_spmv_long_finish(const uint32_t *__restrict__ long_row, const uint32_t *__restrict__ long_first_chunk,
+                   const fe *__restrict__ partial, fe *__restrict__ out, uint32_t n_long, uint32_t n_chunks, uint32_t out_stride) {
+    __shared__ uint32_t sh[8][256];
+    const uint32_t i = blockIdx.x;
     if (i >= n_long) return;
     partial += (size_t)blockIdx.y * n_chunks; out += (size_t)blockIdx.y * out_stride;
     fe acc = Fr::zero();
-    for (uint32_t k = long_first_chunk[i]; k < long_first_chunk[i + 1]; k++) acc = Fr::add(acc, partial[k]);
-    out[long_row[i]] = acc;
+    for (uint32_t k = long_first_chunk[i] + threadIdx.x; k < long_first_chunk[i + 1]; k += blockDim.x) acc = Fr::add(acc, partial[k]);
+#pragma unroll
+    for (int l = 0; l < 8; l++) sh[l][threadIdx.x] = acc.l[l];
+    __syncthreads();
+    for (uint32_t s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            fe o;
+#pragma unroll
+            for (int l = 0; l < 8; l++) o.l[l] = sh[l][threadIdx.x + s];
+            acc = Fr::add(acc, o);
+#pragma unroll
+            for (int l = 0; l < 8; l++) sh[l][threadIdx.x] = acc.l[l];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[long_row[i]] = acc;
 }
 
 // aA[nC + i] = w[i], i = 0..nIn  (input-consistency rows, Appendix A.3 step 1); rest of the pad stays 0

@@ -441,7 +441,7 @@ struct DevCsr {
         if (n_chunks) {
             ZK_LAUNCH_SYNC(k_spmv_long_chunks, dim3(n_chunks, batch), 256, st, (const uint32_t *)chunk_begin, (const uint32_t *)chunk_end,
                            (const uint32_t *)col, (const fe *)coeff, w, partial, w_stride);
-            ZK_LAUNCH(k_spmv_long_finish, dim3(zk_div_up(n_long, 64), batch), 64, st, (const uint32_t *)long_row, (const uint32_t *)long_first,
+            ZK_LAUNCH_SYNC(k_spmv_long_finish, dim3(n_long, batch), 256, st, (const uint32_t *)long_row, (const uint32_t *)long_first,
                       (const fe *)partial, out, n_long, n_chunks, out_stride);
         }
         ZK_HIP(hipGetLastError());
