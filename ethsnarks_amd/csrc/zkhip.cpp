@@ -199,7 +199,8 @@ extern "C" const void *zk_pk_part(const zk_pk *pk, int which) {
     case 9: return pk->H.data(); case 10: return pk->L.data(); default: return nullptr;
     }
 }
-extern "C" void zk_pk_free(zk_pk *pk) { delete pk; }
+namespace { void tables_drop_key(uint64_t pk_id); }
+extern "C" void zk_pk_free(zk_pk *pk) { if (pk) tables_drop_key(pk->id); delete pk; }
 
 // ---- .raw stream under BINARY_OUTPUT + MONTGOMERY_OUTPUT + NO_PT_COMPRESSION (CMakeLists.txt:115-131,186-188):
 // point = ASCII '0'/'1' infinity flag + raw Montgomery limbs (G1: X Y; G2: X.c0 X.c1 Y.c0 Y.c1); infinity carries affine
@@ -488,6 +489,7 @@ struct DeviceTables {
     uint32_t *posA = nullptr, *posB = nullptr;         // window position -> entry of this shard's query (0xffffffff: none); nullptr: position - offX
     uint32_t offA = 0, offB = 0, offL = 0;
     uint32_t cW = 0;                                   // window bits of the shared witness sort and of the tables it drives
+    bool key_alive = true;                             // false once zk_pk_free has run: the last context to go takes the tables along
     int refs = 0;
 };
 std::mutex g_tables_mu;
@@ -506,10 +508,29 @@ int build_table(typename C::Affine **out, const typename C::Affine *host_bases, 
     tmp.release();
     return rc;
 }
+void tables_free_locked(DeviceTables *t);
+// The tables belong to the KEY, not to the contexts that use them: the last context of a key leaves them in place (its next context -- the
+// next leg of a benchmark, the next request -- finds them instead of expanding 5-20 GB again) and zk_pk_free drops them.
 void tables_release(DeviceTables *t) {
     if (!t) return;
     std::lock_guard<std::mutex> lk(g_tables_mu);
-    if (--t->refs > 0) return;
+    if (--t->refs <= 0 && !t->key_alive) tables_free_locked(t);
+}
+void tables_drop_key(uint64_t pk_id) {                  // zk_pk_free: every idle table set of the key, on every device
+    std::lock_guard<std::mutex> lk(g_tables_mu);
+    for (size_t i = 0; i < g_tables.size();) {
+        DeviceTables *t = g_tables[i];
+        if (t->pk_id == pk_id && t->refs <= 0) tables_free_locked(t);
+        else { if (t->pk_id == pk_id) t->key_alive = false; i++; }
+    }
+}
+// make room: drop the idle table sets of OTHER keys (least recently created first); true if something was freed
+bool tables_evict_idle_locked(uint64_t keep_pk) {
+    for (size_t i = 0; i < g_tables.size(); i++)
+        if (g_tables[i]->refs <= 0 && g_tables[i]->pk_id != keep_pk) { tables_free_locked(g_tables[i]); return true; }
+    return false;
+}
+void tables_free_locked(DeviceTables *t) {
     hipSetDevice(t->device);
     void *dev[] = {t->tA, t->tH, t->tL, t->tB, t->dA_idx, t->dB_idx, t->posA, t->posB};
     for (void *p : dev) if (p) hipFree(p);
@@ -653,6 +674,11 @@ static int ctx_build(zk_ctx *c, const zk_pk *pk, const zk_csr *A, const zk_csr *
             t->share_B = can_share && c->rB.n() >= dense;
             t->share_L = can_share && c->rL.n() >= dense;
             if ((int)t->share_A + (int)t->share_B + (int)t->share_L < 2) t->share_A = t->share_B = t->share_L = false;   // nothing to share
+            {   // make room for this key's tables (5 GB at 2^20, 20 GB at 2^22): idle table sets of other keys go first
+                const uint64_t need = 16ull * (64ull * ((uint64_t)c->rA.n() + c->rH.n() + c->rL.n()) + 128ull * c->rB.n());
+                size_t mem_free = 0, mem_total = 0;
+                while (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess && need + (8ull << 30) > mem_free && tables_evict_idle_locked(pk->id)) {}
+            }
             auto window = [&](uint32_t n) { return t->cbits ? t->cbits : MsmShape::pick_c(n ? n : 1, t->max_batch); };
             t->cW = window(t->win_n);
             t->cA = t->share_A ? t->cW : window(c->rA.n()); t->cB = t->share_B ? t->cW : window(c->rB.n());

@@ -156,6 +156,7 @@ template <class T> hipError_t hipMalloc(T **p, size_t n) { *p = (T *)calloc(n ? 
 inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
 template <class T> hipError_t hipHostMalloc(T **p, size_t n, unsigned = 0) { *p = (T *)calloc(n ? n : 1, 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
+inline hipError_t hipMemGetInfo(size_t *f, size_t *t) { *f = *t = (size_t)1 << 40; return hipSuccess; }
 enum { hipHostRegisterDefault = 0 };
 inline hipError_t hipHostRegister(void *, size_t, unsigned) { return hipSuccess; }
 inline hipError_t hipHostUnregister(void *) { return hipSuccess; }
