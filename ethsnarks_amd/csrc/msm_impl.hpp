@@ -453,13 +453,16 @@ int MsmWork<C>::enqueue_reduce(const SortView &v, hipStream_t st, hipStream_t st
     const uint64_t max_seg = sh.chunk.max_chunks(v.entries_bound);
     if (max_seg + nb + 1 > sh.chunk.max_chunks(sh.max_entries() * max_batch) + (uint64_t)sh.nb * max_batch + 1) return fail_msg(ZK_ERR_ARG, "MSM reduce: the driving sort has more entries than this MSM was allocated for");
     ZK_HIP(hipEventRecord(ev_acc0, st));
+    bool pairs = false;
+    if constexpr (C::WAVES_PER_SIMD_PAIRS != C::WAVES_PER_SIMD) pairs = sh.acc_pairs;      // (only a curve whose pairs form differs gets that kernel: G1)
     if (sh.quad_acc == 4)
         ZK_LAUNCH((k_msm_accumulate<C, 4>), zk_div_up(max_seg * 4, 64), 64, st, (const typename C::Affine *)table, v.sorted, v.off,
                   nb, sh.chunk, v.remap_src, v.remap_offset, v.remap_pos, table_n, v.remap_kbits, pieces);
-    else if (sh.acc_pairs && C::WAVES_PER_SIMD_PAIRS != C::WAVES_PER_SIMD)
-        ZK_LAUNCH((k_msm_accumulate<C, 2>), zk_div_up(max_seg, 64), 64, st, (const typename C::Affine *)table, v.sorted, v.off,
-                  nb, sh.chunk, v.remap_src, v.remap_offset, v.remap_pos, table_n, v.remap_kbits, pieces);
-    else
+    else if (pairs) {
+        if constexpr (C::WAVES_PER_SIMD_PAIRS != C::WAVES_PER_SIMD)
+            ZK_LAUNCH((k_msm_accumulate<C, 2>), zk_div_up(max_seg, 64), 64, st, (const typename C::Affine *)table, v.sorted, v.off,
+                      nb, sh.chunk, v.remap_src, v.remap_offset, v.remap_pos, table_n, v.remap_kbits, pieces);
+    } else
         ZK_LAUNCH((k_msm_accumulate<C, 1>), zk_div_up(max_seg, 64), 64, st, (const typename C::Affine *)table, v.sorted, v.off,
                   nb, sh.chunk, v.remap_src, v.remap_offset, v.remap_pos, table_n, v.remap_kbits, pieces);
     ZK_HIP(hipEventRecord(ev_acc1, st));

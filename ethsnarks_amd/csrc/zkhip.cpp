@@ -1450,6 +1450,15 @@ k_witness_tape(const uint32_t *__restrict__ tape, uint32_t n_records, const fe *
 #pragma unroll
         for (uint32_t i = 0; i < WP_WORDS; i++) nx[i] = nrec[i];
         const uint32_t head = rec[0], target = rec[1], inv_idx = rec[2], out_slot = rec[3];
+        if ((head >> 26) & 1u) {                                 // HINT record (zk_wplan_create_hinted): values the constraints only CHECK
+            // ZK_WHINT_BITS: w[first + i] = bit i of the canonical value of w[src], i < count (field2bits-style gadgets: the bits are
+            // non-deterministic advice, the constraints b (1 - b) = 0 and sum 2^i b_i = x that follow verify them)
+            const uint32_t src = target, first = inv_idx, count = out_slot;
+            const fe v = Fr::from_mont(x[src]);
+            const fe one = Fr::one(), zero = Fr::zero();
+            if (live) for (uint32_t i = 0; i < count; i++) x[first + i] = (i < 256 && ((v.l[i >> 5] >> (i & 31)) & 1u)) ? one : zero;
+            continue;
+        }
         const uint32_t nA = head & 0xffu, nB = (head >> 8) & 0xffu, nC = (head >> 16) & 0xffu;
         if (nA > 0) ZK_WP_TERM(lcA, eA, rec[WP_A + 0], rec[WP_A + 1])
         if (nA > 1) ZK_WP_TERM(lcA, eA, rec[WP_A + 2], rec[WP_A + 3])
@@ -1490,7 +1499,11 @@ struct zk_wplan {
 
 extern "C" int zk_wplan_create(const zk_csr *A, const zk_csr *B, const zk_csr *C, uint32_t nC, uint32_t V,
                                const uint8_t *known, int device, zk_wplan **out) {
-    if (!A || !B || !C || !known || !out) return fail(ZK_ERR_ARG, "null argument");
+    return zk_wplan_create_hinted(A, B, C, nC, V, known, nullptr, 0, device, out);
+}
+extern "C" int zk_wplan_create_hinted(const zk_csr *A, const zk_csr *B, const zk_csr *C, uint32_t nC, uint32_t V,
+                                      const uint8_t *known, const zk_whint *hints, uint32_t n_hints, int device, zk_wplan **out) {
+    if (!A || !B || !C || !known || !out || (n_hints && !hints)) return fail(ZK_ERR_ARG, "null argument");
     if (A->n_rows != nC || B->n_rows != nC || C->n_rows != nC) return fail(ZK_ERR_ARG, "CSR row counts must equal nC");
     if (V >= (1u << 28)) return fail(ZK_ERR_ARG, "witness plan: more than 2^28 variables");
     ZK_TRY(use_device(device));
@@ -1503,24 +1516,47 @@ extern "C" int zk_wplan_create(const zk_csr *A, const zk_csr *B, const zk_csr *C
         coefs.push_back(c); return (uint32_t)coefs.size() - 1;
     };
     const fe one = Fr::one(), minus_one = Fr::neg(one);
+    // hints: variable -> the hint that defines it; a hint runs right before the first constraint that reads one of its variables
+    std::vector<uint32_t> hint_of((size_t)V + 1, 0xffffffffu);
+    std::vector<uint8_t> hint_done(n_hints, 0);
+    for (uint32_t h = 0; h < n_hints; h++) {
+        if (hints[h].kind != ZK_WHINT_BITS) return fail(ZK_ERR_ARG, "witness plan: unknown hint kind");
+        if (hints[h].src > V || hints[h].count == 0 || (uint64_t)hints[h].first + hints[h].count > (uint64_t)V + 1 || hints[h].first == 0) return fail(ZK_ERR_ARG, "witness plan: hint variables out of range");
+        for (uint32_t i = 0; i < hints[h].count; i++) {
+            if (have[hints[h].first + i] || hint_of[hints[h].first + i] != 0xffffffffu) return fail(ZK_ERR_ARG, "witness plan: a hint defines a variable that is supplied or defined twice");
+            hint_of[hints[h].first + i] = h;
+        }
+    }
+    char msg[200];
+    auto try_hint = [&](uint32_t v) -> bool {                      // can a hint supply v now?  then emit its record
+        const uint32_t h = v <= V ? hint_of[v] : 0xffffffffu;
+        if (h == 0xffffffffu || hint_done[h] || !have[hints[h].src]) return false;
+        uint32_t rec[WP_WORDS] = {0};
+        rec[0] = 1u << 26; rec[1] = hints[h].src; rec[2] = hints[h].first; rec[3] = hints[h].count;
+        tape.insert(tape.end(), rec, rec + WP_WORDS);
+        for (uint32_t i = 0; i < hints[h].count; i++) have[hints[h].first + i] = 1;      // (in memory only: the first read of each goes through the cache fill)
+        hint_done[h] = 1;
+        return true;
+    };
     // the kernel's per-lane cache of WP_SLOTS witness values, simulated here: which variable sits in which slot, least recently used out
     uint32_t slot_var[WP_SLOTS]; uint64_t slot_used[WP_SLOTS]; uint64_t tick = 0;
     for (uint32_t i = 0; i < WP_SLOTS; i++) { slot_var[i] = 0xffffffffu; slot_used[i] = 0; }
     auto cache_find = [&](uint32_t v) -> int { for (uint32_t i = 0; i < WP_SLOTS; i++) if (slot_var[i] == v) { slot_used[i] = ++tick; return (int)i; } return -1; };
     auto cache_alloc = [&](uint32_t v) -> uint32_t { uint32_t best = 0; for (uint32_t i = 1; i < WP_SLOTS; i++) if (slot_used[i] < slot_used[best]) best = i;
                                                      slot_var[best] = v; slot_used[best] = ++tick; return best; };
-    char msg[200];
     for (uint32_t j = 0; j < nC; j++) {
         const zk_csr *M[2] = {A, B};
         for (int q = 0; q < 2; q++)
             for (uint32_t e = M[q]->row_ptr[j]; e < M[q]->row_ptr[j + 1]; e++) {
                 if (M[q]->col[e] > V) return fail(ZK_ERR_ARG, "CSR column index exceeds the number of variables");
+                if (!have[M[q]->col[e]]) try_hint(M[q]->col[e]);
                 if (!have[M[q]->col[e]]) { snprintf(msg, sizeof(msg), "constraint %u reads variable %u in %c before anything defines it: not in solved order", j, M[q]->col[e], q ? 'B' : 'A'); return fail(ZK_ERR_ARG, msg); }
             }
         uint32_t target = 0xffffffffu; fe tcoef = one;
         for (uint32_t e = C->row_ptr[j]; e < C->row_ptr[j + 1]; e++) {
             const uint32_t v = C->col[e];
             if (v > V) return fail(ZK_ERR_ARG, "CSR column index exceeds the number of variables");
+            if (!have[v]) try_hint(v);
             if (have[v]) continue;
             if (target != 0xffffffffu) { snprintf(msg, sizeof(msg), "constraint %u introduces two new variables (%u and %u)", j, target, v); return fail(ZK_ERR_ARG, msg); }
             fe cf; memcpy(cf.l, C->coeff + 4 * (size_t)e, 32);
@@ -1538,19 +1574,14 @@ extern "C" int zk_wplan_create(const zk_csr *A, const zk_csr *B, const zk_csr *C
                 if (q == 2 && col == target) continue;
                 fe cf; memcpy(cf.l, Ms[q]->coeff + 4 * (size_t)e, 32);
                 if (Fr::is_zero(cf)) continue;
-                uint32_t kind, ci = 0, slot1 = 0, fill = 0;
+                uint32_t kind, ci = 0;
                 if (col == 0) { kind = 3; ci = coef_index(cf); }                    // coef * ONE: the coefficient itself
-                else {
-                    if (Fr::eq(cf, one)) kind = 0;
-                    else if (Fr::eq(cf, minus_one)) kind = 1;
-                    else { kind = 2; ci = coef_index(cf); }
-                    const int hit = cache_find(col);
-                    if (hit >= 0) slot1 = (uint32_t)hit + 1;
-                    else { slot1 = cache_alloc(col) + 1; fill = 1; }                // from memory this once, then from the cache
-                }
+                else if (Fr::eq(cf, one)) kind = 0;
+                else if (Fr::eq(cf, minus_one)) kind = 1;
+                else { kind = 2; ci = coef_index(cf); }
                 if (ci >= (1u << 24)) return fail(ZK_ERR_ARG, "witness plan: more than 2^24 distinct coefficients");
-                terms[q].push_back(col | kind << 28 | fill << 30);
-                terms[q].push_back(ci | slot1 << 24);
+                terms[q].push_back(col | kind << 28);                               // (the cache slot is decided when the term's record is laid out)
+                terms[q].push_back(ci);
             }
         // records of at most WP_NA / WP_NB / WP_NC terms; all but the last are partial
         size_t done[3] = {0, 0, 0};
@@ -1562,7 +1593,16 @@ extern "C" int zk_wplan_create(const zk_csr *A, const zk_csr *B, const zk_csr *C
             for (int q = 0; q < 3; q++) {
                 const size_t left = terms[q].size() / 2 - done[q];
                 n[q] = (uint32_t)(left < cap[q] ? left : cap[q]);
-                for (uint32_t t = 0; t < 2 * n[q]; t++) rec[at[q] + t] = terms[q][2 * done[q] + t];
+                for (uint32_t t = 0; t < n[q]; t++) {               // the cache is simulated in the order the kernel evaluates: record by record
+                    uint32_t w0 = terms[q][2 * (done[q] + t)], w1 = terms[q][2 * (done[q] + t) + 1];
+                    if (((w0 >> 28) & 3u) != 3) {
+                        const uint32_t col = w0 & 0x0fffffffu;
+                        const int hit = cache_find(col);
+                        if (hit >= 0) w1 |= ((uint32_t)hit + 1) << 24;
+                        else { w1 |= (cache_alloc(col) + 1) << 24; w0 |= 1u << 30; }    // from memory this once (fill), then from the cache
+                    }
+                    rec[at[q] + 2 * t] = w0; rec[at[q] + 2 * t + 1] = w1;
+                }
                 done[q] += n[q];
                 more |= done[q] < terms[q].size() / 2;
             }

@@ -373,3 +373,33 @@ def mimc_preimage_circuit(n_words=11, seed=7):
     pb.add_r1cs_constraint(V(g.result()), 1, V(out))
     r1cs, w = pb.to_r1cs()
     return r1cs, w, digest
+
+
+def field2bits_circuit(n_bits=253, value=None, seed=5):
+    """A circuit with NON-DETERMINISTIC advice, shaped like the reference's field2bits gadgets (src/gadgets/field2bits_strict.cpp without
+    the strict range comparison): public x, bits b_0 .. b_{n-1} with  b_i (1 - b_i) = 0  and  (sum 2^i b_i) * 1 = x,  then the bits are USED:
+    lo = b_0 + 2 b_1 + 4 b_2,  y = lo * x,  digest = MiMC-e7 hash of (y, x).  The constraint system alone does not tell a forward
+    substitution what the bits are -- zk_wplan needs the ZK_WHINT_BITS hint (src = x, first = b_0, count = n_bits).
+    Returns (R1CS, witness, (x_var, first_bit_var, n_bits))."""
+    from .r1cs import SplitMix64
+    if value is None:
+        value = SplitMix64(seed).fr() % (1 << n_bits)
+    assert 0 <= value < (1 << n_bits) and (1 << n_bits) <= FR
+    pb = Protoboard()
+    x = pb.allocate(value)
+    pb.set_input_sizes(1)
+    bits = pb.allocate_array(n_bits, [(value >> i) & 1 for i in range(n_bits)])
+    for b in bits:
+        pb.add_r1cs_constraint(V(b), lc_add(1, lc_scale(V(b), FR - 1)), 0)          # b (1 - b) = 0
+    pb.add_r1cs_constraint({b: (1 << i) % FR for i, b in enumerate(bits)}, 1, V(x))     # the bits spell x
+    lo = (value & 7) if n_bits >= 3 else value
+    y = pb.allocate(lo * value % FR)
+    pb.add_r1cs_constraint({b: 1 << i for i, b in enumerate(bits[:3])}, V(x), V(y))
+    iv = pb.allocate(0)
+    pb.add_r1cs_constraint(V(iv), 1, 0)                                               # iv = 0 (a checked constant)
+    g = MiMCe7HashGadget(pb, iv, [y, x])
+    g.generate_r1cs_witness()
+    g.generate_r1cs_constraints()
+    r1cs, w = pb.to_r1cs()
+    assert pb.is_satisfied()
+    return r1cs, w, (x, bits[0], n_bits)

@@ -63,7 +63,7 @@ EXPORTS = [
     "zk_domain_size", "zk_ctx_create", "zk_ctx_create_sized", "zk_ctx_destroy",
     "zk_prove", "zk_prove_timed", "zk_prove_partial", "zk_prove_partial_timed", "zk_prove_combine", "zk_prove_submit", "zk_prove_collect", "zk_proof_to_json",
     "zk_prove_batch", "zk_prove_batch_submit", "zk_prove_batch_submit_resident", "zk_prove_batch_collect",
-    "zk_wplan_create", "zk_wplan_solve", "zk_wplan_free", "zk_dev_alloc", "zk_dev_free", "zk_dev_upload", "zk_dev_download",
+    "zk_wplan_create", "zk_wplan_create_hinted", "zk_wplan_solve", "zk_wplan_free", "zk_dev_alloc", "zk_dev_free", "zk_dev_upload", "zk_dev_download",
     "zk_chain_submit", "zk_chain_device", "zk_h_from_chains_submit", "zk_h_device", "zk_chain_wait", "zk_prove_submit_with_h", "zk_prove_submit_defer_h", "zk_prove_submit_h", "zk_prove_abort",
     "zk_prove_submit_pinned", "zk_prove_batch_submit_pinned", "zk_host_alloc", "zk_host_free", "zk_host_register", "zk_host_unregister",
     "zk_prove_submit_resident", "zk_prove_stage", "zk_prove_stage_pinned", "zk_prove_submit_staged", "zk_ctx_info", "zk_ctx_partials_device", "zk_prove_collect_device", "zk_prove_combine_device", "zk_launch_count", "zk_profile_begin", "zk_profile_end", "zk_device_info", "zk_device_pci_bus_id",
@@ -623,15 +623,18 @@ class WitnessPlan:
     """zk_wplan: the constraint system as a witness program (forward substitution), run on the GPU for k witnesses at a time.
     `known`: indices of the variables the caller supplies (ONE is implied)."""
 
-    def __init__(self, r1cs, known, device=0):
+    def __init__(self, r1cs, known, device=0, bit_hints=()):
+        """bit_hints: (src, first, count) triples -- w[first + i] = bit i of w[src] (ZK_WHINT_BITS: advice the constraints only check)"""
         lib = load_library(_lib_path_loaded)
         flags = np.zeros(r1cs.V + 1, dtype=np.uint8)
         flags[np.asarray(list(known), dtype=np.int64)] = 1
         keep = []
         a, b, c = _csr_structs(r1cs, keep)
         h = C.c_void_p()
-        _check(lib.zk_wplan_create(C.byref(a), C.byref(b), C.byref(c), C.c_uint32(r1cs.nC), C.c_uint32(r1cs.V),
-                                   flags.ctypes.data_as(C.POINTER(C.c_uint8)), device, C.byref(h)))
+        hints = np.asarray([[1, s_, f_, n_] for s_, f_, n_ in bit_hints], dtype=np.uint32).reshape(-1, 4)
+        _check(lib.zk_wplan_create_hinted(C.byref(a), C.byref(b), C.byref(c), C.c_uint32(r1cs.nC), C.c_uint32(r1cs.V),
+                                          flags.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                          hints.ctypes.data_as(C.c_void_p) if len(hints) else None, C.c_uint32(len(hints)), device, C.byref(h)))
         self._h, self.r1cs = h, r1cs
 
     def solve(self, device_ptr, k):

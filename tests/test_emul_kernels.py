@@ -290,3 +290,36 @@ def test_witness_plan_completes_witnesses_on_the_device(zk, oracle):
         zk.WitnessPlan(r, supplied[:-1])                            # a message word neither supplied nor defined
     assert e.value.code == 1 and "solved order" in str(e.value)
     ctx.close(); plan.close(); buf.free()
+
+
+def test_witness_plan_with_bit_decomposition_hints(zk, oracle):
+    """Gadgets with non-deterministic advice (the reference's field2bits family): the constraints only CHECK the bits, so the forward
+    substitution needs a hint -- ZK_WHINT_BITS: w[first + i] = bit i of w[src].  With it the plan completes the witness from x alone
+    (equal to the front end's, proof equal to the oracle's); without it the system is refused."""
+    from ethsnarks_amd import gadgets as G
+    k = 3
+    cases = [G.field2bits_circuit(64, seed=40 + p) for p in range(k)]
+    r, (xv, first, nb) = cases[0][0], cases[0][2]
+    iv = first + nb + 1                                              # allocation order: x, bits, y, iv, ...
+    supplied = [0, xv, iv]
+    with pytest.raises(zk.ZkError) as e:
+        zk.WitnessPlan(r, supplied)
+    assert "solved order" in str(e.value)
+    plan = zk.WitnessPlan(r, supplied, bit_hints=[(xv, first, nb)])
+    start = np.zeros((k, r.V + 1, 4), dtype=np.uint64)
+    for p in range(k):
+        start[p, supplied] = F.fr_to_mont([cases[p][1][i] for i in supplied])
+    buf = zk.DeviceBuffer(32 * (r.V + 1) * k)
+    buf.upload(start)
+    assert plan.solve(buf.ptr, k) == 0
+    got = buf.download((k, r.V + 1, 4))
+    for p in range(k):
+        assert np.array_equal(got[p], F.fr_to_mont(cases[p][1]))
+    pk_o, _ = oracle.keygen(r, seed=8)
+    pk = zk.ProvingKey.from_parts(**pk_o.parts())
+    ctx = zk.ProverContext(pk, r, max_batch=k)
+    ctx.submit_batch(None, device_ptr=buf.ptr, k=k)
+    parts, _ = ctx.collect_batch(k)
+    for p in range(k):
+        assert zk.proof_to_json(ctx.prove_combine(parts[p]), got[p][1:2]) == oracle.prove(pk_o, r, got[p])[0]
+    ctx.close(); plan.close(); buf.free()

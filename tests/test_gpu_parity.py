@@ -319,6 +319,37 @@ def test_witness_plan_merkle29_on_device_then_batch_prove(hip, oracle):
     ctx.close(); plan.close(); buf.free()
 
 
+def test_witness_plan_with_bit_decomposition_hints(hip, oracle):
+    """Gadgets with non-deterministic advice (the reference's field2bits family, src/gadgets/field2bits_strict.cpp): the constraints only
+    CHECK the bits, so the witness program needs a hint -- ZK_WHINT_BITS: w[first + i] = bit i of w[src].  253-bit decomposition (a
+    253-term row: many tape records with carried sums), k witnesses completed from x alone, proofs equal to the oracle's."""
+    from ethsnarks_amd import gadgets as G
+    k = 4
+    cases = [G.field2bits_circuit(253, seed=90 + p) for p in range(k)]
+    r, (xv, first, nb) = cases[0][0], cases[0][2]
+    supplied = [0, xv, first + nb + 1]                               # ONE, x, iv (allocation order: x, bits, y, iv, ...)
+    with pytest.raises(hip.ZkError):
+        hip.WitnessPlan(r, supplied)                                 # not in solved order without the hint
+    plan = hip.WitnessPlan(r, supplied, bit_hints=[(xv, first, nb)])
+    start = np.zeros((k, r.V + 1, 4), dtype=np.uint64)
+    for p in range(k):
+        start[p, supplied] = F.fr_to_mont([cases[p][1][i] for i in supplied])
+    buf = hip.DeviceBuffer(32 * (r.V + 1) * k)
+    buf.upload(start)
+    assert plan.solve(buf.ptr, k) == 0
+    got = buf.download((k, r.V + 1, 4))
+    for p in range(k):
+        assert np.array_equal(got[p], F.fr_to_mont(cases[p][1]))
+    pk, _ = hip.keygen(r, seed=31)
+    pk_o = oracle.pk_from_parts(pk.parts())
+    ctx = hip.ProverContext(pk, r, max_batch=k)
+    ctx.submit_batch(None, device_ptr=buf.ptr, k=k)
+    parts, _ = ctx.collect_batch(k)
+    for p in range(k):
+        assert hip.proof_to_json(ctx.prove_combine(parts[p]), got[p][1:2]) == oracle.prove(pk_o, r, got[p])[0]
+    ctx.close(); plan.close(); buf.free()
+
+
 def test_prove_batch_chain_shared_sort_and_odd_batch(hip, oracle):
     """dense queries (A-, B-, L-query on one shared witness sort), a batch that is not a power of two, the asynchronous form"""
     r, _ = R.synthetic_chain((1 << 12) - 2, 1)
