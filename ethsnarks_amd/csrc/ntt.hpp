@@ -232,12 +232,15 @@ static ZK_HD bool fr_is_one(const fe &a) {
 static ZK_D fe spmv_term(const fe &coef, const fe &x) { return fr_is_one(coef) ? x : Fr::mul(coef, x); }
 
 // blockIdx.y = proof of a batch: its witness lies w_stride elements, its output out_stride elements further on
+// The same launch writes the PADDING of the polynomial: rows [n_rows, m_rows) are zero, except -- the A polynomial, n_in_rows = nIn + 1 --
+// the input-consistency rows aA[nC + i] = w[i] (Appendix A.3 step 1).  (A memset and a kernel of their own until round 3.)
 __global__ void k_spmv_rows(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ col,
                             const fe *__restrict__ coeff, const fe *__restrict__ w, fe *__restrict__ out, uint32_t n_rows,
-                            uint32_t w_stride, uint32_t out_stride) {
+                            uint32_t w_stride, uint32_t out_stride, uint32_t m_rows, uint32_t n_in_rows) {
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n_rows) return;
+    if (j >= m_rows) return;
     w += (size_t)blockIdx.y * w_stride; out += (size_t)blockIdx.y * out_stride;
+    if (j >= n_rows) { out[j] = j - n_rows < n_in_rows ? w[j - n_rows] : Fr::zero(); return; }
     uint32_t b = row_ptr[j], e = row_ptr[j + 1];
     if (e - b > SPMV_LONG_ROW) return;                     // written by k_spmv_long_finish
     fe acc = Fr::zero();
@@ -298,12 +301,6 @@ k_spmv_long_finish(const uint32_t *__restrict__ long_row, const uint32_t *__rest
         __syncthreads();
     }
     if (threadIdx.x == 0) out[long_row[i]] = acc;
-}
-
-// aA[nC + i] = w[i], i = 0..nIn  (input-consistency rows, Appendix A.3 step 1); rest of the pad stays 0
-__global__ void k_set_input_rows(fe *aA, const fe *w, uint32_t nC, uint32_t nIn, uint32_t w_stride, uint32_t out_stride) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i <= nIn) aA[(size_t)blockIdx.y * out_stride + nC + i] = w[(size_t)blockIdx.y * w_stride + i];
 }
 
 }  // namespace zk

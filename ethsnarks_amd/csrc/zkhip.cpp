@@ -437,8 +437,10 @@ struct DevCsr {
         return ZK_OK;
     }
     // out[p][0..n_rows) = M * w[p] for the `batch` witnesses w_stride elements apart (outputs out_stride apart)
-    int enqueue(const fe *w, fe *out, hipStream_t st, uint32_t batch, uint32_t w_stride, uint32_t out_stride) const {
-        if (n_rows) ZK_LAUNCH(k_spmv_rows, dim3(zk_div_up(n_rows, 256), batch), 256, st, (const uint32_t *)row_ptr, (const uint32_t *)col, (const fe *)coeff, w, out, n_rows, w_stride, out_stride);
+    // m_rows >= n_rows: rows [n_rows, m_rows) of `out` are written too: the first n_in_rows of them w[0 ..), the rest zero (the polynomial's padding)
+    int enqueue(const fe *w, fe *out, hipStream_t st, uint32_t batch, uint32_t w_stride, uint32_t out_stride, uint32_t m_rows = 0, uint32_t n_in_rows = 0) const {
+        if (m_rows < n_rows) m_rows = n_rows;
+        if (m_rows) ZK_LAUNCH(k_spmv_rows, dim3(zk_div_up(m_rows, 256), batch), 256, st, (const uint32_t *)row_ptr, (const uint32_t *)col, (const fe *)coeff, w, out, n_rows, w_stride, out_stride, m_rows, n_in_rows);
         if (n_chunks) {
             ZK_LAUNCH_SYNC(k_spmv_long_chunks, dim3(n_chunks, batch), 256, st, (const uint32_t *)chunk_begin, (const uint32_t *)chunk_end,
                            (const uint32_t *)col, (const fe *)coeff, w, partial, w_stride);
@@ -821,13 +823,9 @@ extern "C" void zk_ctx_destroy(zk_ctx *ctx) { delete ctx; }
 static int enqueue_compute_h(zk_ctx *c, hipStream_t st) {
     const uint32_t m = c->m, k = c->cur_batch, ws = c->V + 1;
     fe *a = c->d_a, *b = c->d_a + (size_t)m * k, *cc = c->d_a + 2 * (size_t)m * k;
-    // rows [nC, m) of every polynomial are padding (the input-consistency rows of A are set below): only they need zeroing,
-    // the row evaluations write every row below nC
-    if (m > c->nC) ZK_HIP(hipMemset2DAsync(a + c->nC, 32 * (size_t)m, 0, 32 * (size_t)(m - c->nC), 3 * (size_t)k, st));
-    ZK_TRY(c->cA.enqueue(c->d_w, a, st, k, ws, m));
-    ZK_TRY(c->cB.enqueue(c->d_w, b, st, k, ws, m));
-    ZK_TRY(c->cC.enqueue(c->d_w, cc, st, k, ws, m));
-    ZK_LAUNCH(k_set_input_rows, dim3(zk_div_up(c->nIn + 1, 64), k), 64, st, a, (const fe *)c->d_w, c->nC, c->nIn, ws, m);
+    ZK_TRY(c->cA.enqueue(c->d_w, a, st, k, ws, m, m, c->nIn + 1));         // (the row kernels write the padding and A's input-consistency rows too)
+    ZK_TRY(c->cB.enqueue(c->d_w, b, st, k, ws, m, m, 0));
+    ZK_TRY(c->cC.enqueue(c->d_w, cc, st, k, ws, m, m, 0));
     // all 3 k polynomials go through each pass together (blockIdx.y): fewer, larger launches
     // SIX transforms, not the reference's seven (libsnark: iFFT and cosetFFT of A, B and C, divide by Z on the coset, icosetFFT): C never
     // goes to the coset.  With P = A B, icosetFFT(P on the coset) is P mod (x^m - g^m) = Z(g) H + C for every witness (deg H, deg C < m,
@@ -852,10 +850,8 @@ static int enqueue_chain(zk_ctx *c, int which) {
     hipStream_t st = c->s_main;
     const uint32_t m = c->m, ws = c->V + 1;
     fe *p = c->d_a + (size_t)which * m, *tmp = c->d_t + (size_t)which * m;
-    if (m > c->nC) ZK_HIP(hipMemsetAsync(p + c->nC, 0, 32 * (size_t)(m - c->nC), st));
     const DevCsr &M = which == 0 ? c->cA : which == 1 ? c->cB : c->cC;
-    ZK_TRY(M.enqueue(c->d_w, p, st, 1, ws, m));
-    if (which == 0) ZK_LAUNCH(k_set_input_rows, dim3(zk_div_up(c->nIn + 1, 64), 1), 64, st, p, (const fe *)c->d_w, c->nC, c->nIn, ws, m);
+    ZK_TRY(M.enqueue(c->d_w, p, st, 1, ws, m, m, which == 0 ? c->nIn + 1 : 0));
     if (which == 2) return ntt_run(c->tab, p, tmp, true, nullptr, c->tab.inv_m_zinv, st);      // C stays in coefficient form, / Z(g) (enqueue_compute_h): at d_t + 2 m
     ZK_TRY(ntt_run(c->tab, p, tmp, true, nullptr, c->tab.inv_then_coset, st));
     ZK_TRY(ntt_run(c->tab, tmp, p, false, nullptr, nullptr, st));
