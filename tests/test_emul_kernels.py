@@ -133,6 +133,43 @@ def test_staged_upload(zk, oracle):
     c.close(); pk.close()
 
 
+def test_pinned_witness_and_two_phase_submit(zk, oracle):
+    """round-3 entry points in the emulation build: the witness read from a zk_host_alloc buffer where it lies (submit / stage), and
+    the two-step submit of sharded latency mode (zk_prove_submit_defer_h -> zk_chain_submit(NULL) -> zk_h_from_chains_submit ->
+    zk_prove_submit_h) on ONE unsharded context, with its state machine: collect refuses a proof without its H part, abort frees it"""
+    r, w = R.random_r1cs(300, 2, seed=15)
+    wm = F.fr_to_mont(w)
+    pk_o, _ = oracle.keygen(r, seed=9)
+    expect = oracle.prove(pk_o, r, wm)[0]
+    pk = zk.ProvingKey.from_parts(**pk_o.parts())
+    c = zk.ProverContext(pk, r)
+    pin = zk.PinnedBuffer(wm.nbytes); pin.array[:] = wm.reshape(-1)
+    c.submit_pinned(pin); c.stage_pinned(pin)
+    part, _ = c.collect()
+    assert zk.proof_to_json(c.prove_combine(part), wm[1:3]) == expect
+    c.submit_staged()
+    part, _ = c.collect()
+    assert zk.proof_to_json(c.prove_combine(part), wm[1:3]) == expect
+    with pytest.raises(zk.ZkError):
+        c.submit_h(c.h_device_ptr())                               # nothing deferred
+    c.submit_defer_h(wm)
+    with pytest.raises(zk.ZkError):
+        c.collect()                                                # no H part yet
+    with pytest.raises(zk.ZkError):
+        c.submit(wm)                                               # a proof is in flight
+    for which in range(3):
+        c.chain_submit(None, which)                                # the deferred proof's witness
+    c.chain_wait()
+    c.h_from_chains_submit(c.chain_device_ptr(0), c.chain_device_ptr(1), c.chain_device_ptr(2))
+    c.chain_wait(check_degree=True)
+    c.submit_h(c.h_device_ptr())
+    part, _ = c.collect()
+    assert zk.proof_to_json(c.prove_combine(part), wm[1:3]) == expect
+    c.submit_defer_h(wm); c.abort()                                # dropped: the context is free again
+    assert zk.prove(c, wm) == expect
+    pin.free(); c.close()
+
+
 def test_prove_chain_long_rows_and_sharding(zk, oracle, tmp_path):
     r, w = R.synthetic_chain(254, 1)                    # last row: 510 terms -> long-row path
     wm = F.fr_to_mont(w)
