@@ -11,8 +11,18 @@
 // every kernel launch goes through this macro: it counts launches, and between zk_profile_begin() / zk_profile_end()
 // (a measurement aid of bench.py, off on the proving path) brackets each launch with a HIP event pair on its stream
 namespace zk { void launch_pre(const char *name, hipStream_t st); void launch_post(hipStream_t st); }
+#ifdef ZK_EXP_MARGINAL
+// measurement build only (tools/build_variant.sh marginal -DZK_EXP_MARGINAL): launches whose name contains one of the ';'-separated
+// substrings of $ZK_EXP_SKIP are dropped once $ZK_EXP_SKIP_AFTER launches have gone by -- bench.py proves the SAME witness every step, so
+// a proof that finds the previous proof's sorted digits / h / bucket sums in its buffers costs what it costs WITHOUT the dropped kernels:
+// the marginal cost of a phase inside the full pipeline
+namespace zk { bool exp_skip(const char *name); }
+#define ZK_LAUNCH(kern, grid, block, stream, ...) \
+    do { if (zk::exp_skip(#kern)) break; zk::launch_pre(#kern, stream); hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, stream, __VA_ARGS__); zk::launch_post(stream); } while (0)
+#else
 #define ZK_LAUNCH(kern, grid, block, stream, ...) \
     do { zk::launch_pre(#kern, stream); hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, stream, __VA_ARGS__); zk::launch_post(stream); } while (0)
+#endif
 #define ZK_LAUNCH_SYNC ZK_LAUNCH
 #endif
 #define ZK_HD __host__ __device__ __forceinline__

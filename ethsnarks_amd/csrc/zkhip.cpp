@@ -48,6 +48,19 @@ void zk::launch_post(hipStream_t st) {
     if (t_pending) { (void)hipEventRecord(t_pending, st); t_pending = nullptr; }
 }
 extern "C" uint64_t zk_launch_count(void) { return g_launches.load(); }
+#ifdef ZK_EXP_MARGINAL
+bool zk::exp_skip(const char *name) {
+    static const char *list = getenv("ZK_EXP_SKIP");
+    static const uint64_t after = getenv("ZK_EXP_SKIP_AFTER") ? strtoull(getenv("ZK_EXP_SKIP_AFTER"), nullptr, 10) : 150;
+    if (!list || !*list || g_launches.load(std::memory_order_relaxed) < after) return false;
+    for (const char *p = list; *p;) {
+        const char *e = strchr(p, ';'); const size_t n = e ? (size_t)(e - p) : strlen(p);
+        if (n && std::string(name).find(std::string(p, n)) != std::string::npos) return true;
+        p += n + (e ? 1 : 0);
+    }
+    return false;
+}
+#endif
 extern "C" int zk_profile_begin(void) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     for (auto &r : g_prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
