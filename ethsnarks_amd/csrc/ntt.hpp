@@ -19,12 +19,17 @@
 
 namespace zk {
 
-constexpr int NTT_TILE_LOG = 11;                 // 2048 elements = 64 KiB of LDS per workgroup
+#ifndef ZK_NTT_TILE_LOG
+#define ZK_NTT_TILE_LOG 11
+#endif
+constexpr int NTT_TILE_LOG = ZK_NTT_TILE_LOG;    // 2048 elements = 64 KiB of LDS per workgroup
 constexpr int NTT_TILE = 1 << NTT_TILE_LOG;
-// threads per workgroup: the 64 KiB tile allows two workgroups per CU, so 1024 threads give 8 waves per SIMD (48 VGPRs) where 512 gave 4:
-// the six transforms at 2^20 0.873 -> 0.840 ms, at 2^18 0.305 -> 0.282 ms (tools/ntt_bench, same box; 256: 0.956 / 0.361)
+// threads per workgroup: every thread keeps FOUR elements in registers through two stages (k_ntt_pass), so 512 threads cover the 2048-element
+// tile; two workgroups per CU (64 KiB each) give 4 waves per SIMD at 92 VGPRs.  tools/ntt_bench, same box, six transforms at 2^20 / 2^18 / 2^22:
+// 0.786 / 0.275 / 3.56 ms against 0.813 / 0.280 / 3.68 ms for one stage per LDS round trip with 1024 threads (round 3 until then; 1024 threads
+// with the paired stages: 0.932 -- half of them idle in a stage pair; 256: 0.843; a 4096-element tile with 1024 threads, one workgroup per CU: 0.852)
 #ifndef ZK_NTT_THREADS
-#define ZK_NTT_THREADS 1024
+#define ZK_NTT_THREADS 512
 #endif
 constexpr int NTT_THREADS = ZK_NTT_THREADS;
 constexpr int NTT_MIN_LOGC = 2;                  // >= 4 columns = 128 contiguous bytes (one cache line) per tile row
@@ -76,7 +81,39 @@ k_ntt_pass(const fe *__restrict__ in, fe *__restrict__ out, const fe *__restrict
         for (int l = 0; l < 8; l++) sh[l][e] = v.l[l];
     }
     __syncthreads();
-    for (uint32_t s = 1; s <= k; s++) {
+    // Stages in PAIRS, four elements per thread in registers (radix 4 with the radix-2 twiddle table): rows q00 < q01 < q10 < q11 differ in bits
+    // s - 1 and s of the row index; stage s multiplies rows q01, q11 by T1 = w_S^j, stage s + 1 rows q10, q11 by T2a = w_{S+1}^j and
+    // T2b = w_{S+1}^(j + 2^(S-1)) = tw[index of T2a + m / 4].  Half the LDS traffic, barriers and index arithmetic of one stage per round trip.
+    uint32_t s = 1;
+    for (; s + 1 <= k; s += 2) {
+        const uint32_t half = 1u << (s - 1), S = s0 + s;
+        for (uint32_t qd = threadIdx.x; qd < (tile >> 2); qd += blockDim.x) {
+            const uint32_t c = qd & (ncol - 1), r = qd >> logc;
+            const uint32_t jm = r & (half - 1), grp = r >> (s - 1);
+            const uint32_t e00 = (((grp << (s + 1)) | jm) << logc) | c, e01 = e00 + (half << logc), e10 = e00 + (half << (logc + 1)), e11 = e10 + (half << logc);
+            const uint32_t j = (jm << s0) | ((lb << logc) | c);
+            const size_t i2 = (size_t)j << (logm - S - 1);             // index of T2a; T1 = T2a^2 sits at 2 i2, T2b at i2 + m / 4
+            fe x0, x1, x2, x3;
+#pragma unroll
+            for (int l = 0; l < 8; l++) { x0.l[l] = sh[l][e00]; x1.l[l] = sh[l][e01]; x2.l[l] = sh[l][e10]; x3.l[l] = sh[l][e11]; }
+#ifdef ZK_NTT_NOPAIR
+            if (S > 1) { const fe t1 = tw[i2 << 1]; x1 = Fr::lmul(x1, t1); x3 = Fr::lmul(x3, t1); }
+#else
+            if (S > 1) { const fe t1 = tw[i2 << 1]; Fr::lmul_pair(x1, t1, x3, t1, x1, x3); }      // stage 1: every twiddle is w^0 = 1 (uniform branch)
+#endif
+            fe a0 = Fr::ladd(x0, x1), a1 = Fr::lsub(x0, x1), a2 = Fr::ladd(x2, x3), a3 = Fr::lsub(x2, x3);
+#ifdef ZK_NTT_NOPAIR
+            a2 = Fr::lmul(a2, tw[i2]); a3 = Fr::lmul(a3, tw[i2 + ((size_t)1 << (logm - 2))]);
+#else
+            Fr::lmul_pair(a2, tw[i2], a3, tw[i2 + ((size_t)1 << (logm - 2))], a2, a3);
+#endif
+            x0 = Fr::ladd(a0, a2); x2 = Fr::lsub(a0, a2); x1 = Fr::ladd(a1, a3); x3 = Fr::lsub(a1, a3);
+#pragma unroll
+            for (int l = 0; l < 8; l++) { sh[l][e00] = x0.l[l]; sh[l][e01] = x1.l[l]; sh[l][e10] = x2.l[l]; sh[l][e11] = x3.l[l]; }
+        }
+        __syncthreads();
+    }
+    if (s <= k) {                                                    // an odd stage count ends with one radix-2 stage
         const uint32_t half = 1u << (s - 1), S = s0 + s;
         for (uint32_t bf = threadIdx.x; bf < (tile >> 1); bf += blockDim.x) {
             uint32_t c = bf & (ncol - 1), q = bf >> logc;
