@@ -29,7 +29,7 @@ def test_field_mul(zk, oracle):
     assert np.array_equal(zk.field_mul(a, b, "fq"), o)
 
 
-@pytest.mark.parametrize("logm", [0, 1, 2, 5, 11, 12, 14])
+@pytest.mark.parametrize("logm", [0, 1, 2, 3, 5, 11, 12, 13, 14])      # stage counts per pass: odd and even, one and several pairs
 def test_ntt(zk, oracle, logm):
     x = F.fr_to_mont(rand_scalars(1 << logm, logm))
     for inv in (False, True):

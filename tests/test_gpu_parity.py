@@ -27,7 +27,7 @@ def test_field_mul(hip, oracle):
     assert np.array_equal(hip.field_mul(a, b, "fq"), o)
 
 
-@pytest.mark.parametrize("logm", [0, 1, 4, 10, 11, 12, 15, 18, 20])
+@pytest.mark.parametrize("logm", [0, 1, 3, 4, 10, 11, 12, 13, 15, 18, 20, 21])   # stage counts per pass: odd and even, one and several pairs, two and three passes
 def test_ntt_vs_oracle(hip, oracle, logm):
     rng = np.random.default_rng(logm)
     x = rng.integers(0, 1 << 62, size=(1 << logm, 4), dtype=np.uint64)
