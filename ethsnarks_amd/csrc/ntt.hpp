@@ -7,10 +7,10 @@
 // Semantics follow SURVEY.md Appendix A.2/A.3: FFT, iFFT (x 1/m), cosetFFT (g = 5), icosetFFT,
 // divide_by_Z_on_coset.
 //
-// Kernel shape (HBM-bound, 32 B elements): a transform of size m = 2^logm is done in passes; each
-// pass loads a tile of 2^TILE_LOG elements into LDS (struct-of-limbs layout: 8 planes of u32, so a
-// wave's 64 lanes hit 64 consecutive banks), runs k butterfly stages there, and writes the tile
-// back.  Pass 0 does the bit-reversal permutation on load, later passes gather NCOL-wide contiguous
+// Kernel shape (32 B elements; bound by the Fr products of the butterflies -- VALU issue -- not by HBM): a transform
+// of size m = 2^logm is done in passes; each pass loads a tile of 2^TILE_LOG elements into LDS (struct-of-limbs layout: 8 planes of u32,
+// so a wave's 64 lanes hit 64 consecutive banks), runs k butterfly stages there -- two per LDS round trip, four elements per thread in
+// registers -- and writes the tile back.  Pass 0 does the bit-reversal permutation on load, later passes gather NCOL-wide contiguous
 // column groups (>= 256 B per row) so that strided stages still move whole cache lines.
 // Scaling vectors (1/m, coset powers) are fused into the first load / last store.
 #pragma once
