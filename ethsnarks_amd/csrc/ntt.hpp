@@ -27,7 +27,8 @@ constexpr int NTT_TILE = 1 << NTT_TILE_LOG;
 // threads per workgroup: every thread keeps FOUR elements in registers through two stages (k_ntt_pass), so 512 threads cover the 2048-element
 // tile; two workgroups per CU (64 KiB each) give 4 waves per SIMD at 92 VGPRs.  tools/ntt_bench, same box, six transforms at 2^20 / 2^18 / 2^22:
 // 0.786 / 0.275 / 3.56 ms against 0.813 / 0.280 / 3.68 ms for one stage per LDS round trip with 1024 threads (round 3 until then; 1024 threads
-// with the paired stages: 0.932 -- half of them idle in a stage pair; 256: 0.843; a 4096-element tile with 1024 threads, one workgroup per CU: 0.852)
+// with the paired stages: 0.932 -- half of them idle in a stage pair; 256: 0.843; a 4096-element tile with 1024 threads, one workgroup per CU: 0.852).
+// With the first stage pair fed from memory and the last step stored to it: 0.792 -> 0.763 / 0.276 -> 0.261 / 3.48 -> 3.24 ms (profiles/r03_ntt_alone.txt)
 #ifndef ZK_NTT_THREADS
 #define ZK_NTT_THREADS 512
 #endif
@@ -71,22 +72,40 @@ k_ntt_pass(const fe *__restrict__ in, fe *__restrict__ out, const fe *__restrict
     const uint32_t lb = blockIdx.x & (nlb - 1), h = blockIdx.x / nlb;
     const uint32_t base = (h << (s0 + k)) | (lb << logc);
 
-    for (uint32_t e = threadIdx.x; e < tile; e += blockDim.x) {
-        uint32_t idx = base | ((e >> logc) << s0) | (e & (ncol - 1));
-        uint32_t src = bitrev_load ? bitrev32(idx, logm) : idx;
+    // element of the tile -> index in the vector; what a pass reads (fetch) and writes (emit) there
+    auto gidx = [&](uint32_t e) -> uint32_t { return base | ((e >> logc) << s0) | (e & (ncol - 1)); };
+    auto fetch = [&](uint32_t idx) -> fe {
+        const uint32_t src = bitrev_load ? bitrev32(idx, logm) : idx;
         fe v = in[src];
         if (fuse.in2) v = Fr::mul(v, fuse.in2[src]);
         if (pre) v = Fr::mul(v, pre[src]);
+        return v;
+    };
+    auto emit = [&](uint32_t idx, fe v) {
+        if (post) v = Fr::mul(v, post[idx]);                    // strict product: canonical whatever the (loose) input
+        else if (last_pass) v = Fr::canon(v);
+        if (fuse.sub) v = Fr::sub(v, fuse.sub[idx]);
+        out[idx] = v;
+    };
+    // The FIRST stage pair takes its four elements straight from memory and the LAST step (a stage pair, or the single stage an odd count ends
+    // with) stores straight to it: two LDS round trips and two barriers less per pass (pass 0 of 2^20: 5 instead of 7, the later pass 4 instead of
+    // 6).  Later passes work in place; a workgroup has read its whole tile before its last step stores.  k < 2: through the tile as before.
+    const bool load_fused = k >= 2;
+    if (!load_fused) {
+        for (uint32_t e = threadIdx.x; e < tile; e += blockDim.x) {
+            const fe v = fetch(gidx(e));
 #pragma unroll
-        for (int l = 0; l < 8; l++) sh[l][e] = v.l[l];
+            for (int l = 0; l < 8; l++) sh[l][e] = v.l[l];
+        }
+        __syncthreads();
     }
-    __syncthreads();
     // Stages in PAIRS, four elements per thread in registers (radix 4 with the radix-2 twiddle table): rows q00 < q01 < q10 < q11 differ in bits
     // s - 1 and s of the row index; stage s multiplies rows q01, q11 by T1 = w_S^j, stage s + 1 rows q10, q11 by T2a = w_{S+1}^j and
     // T2b = w_{S+1}^(j + 2^(S-1)) = tw[index of T2a + m / 4].  Half the LDS traffic, barriers and index arithmetic of one stage per round trip.
     uint32_t s = 1;
     for (; s + 1 <= k; s += 2) {
         const uint32_t half = 1u << (s - 1), S = s0 + s;
+        const bool from_mem = s == 1, to_mem = s + 1 == k;           // (uniform)
         for (uint32_t qd = threadIdx.x; qd < (tile >> 2); qd += blockDim.x) {
             const uint32_t c = qd & (ncol - 1), r = qd >> logc;
             const uint32_t jm = r & (half - 1), grp = r >> (s - 1);
@@ -94,26 +113,35 @@ k_ntt_pass(const fe *__restrict__ in, fe *__restrict__ out, const fe *__restrict
             const uint32_t j = (jm << s0) | ((lb << logc) | c);
             const size_t i2 = (size_t)j << (logm - S - 1);             // index of T2a; T1 = T2a^2 sits at 2 i2, T2b at i2 + m / 4
             fe x0, x1, x2, x3;
+            if (from_mem) { x0 = fetch(gidx(e00)); x1 = fetch(gidx(e01)); x2 = fetch(gidx(e10)); x3 = fetch(gidx(e11)); }
+            else {
 #pragma unroll
-            for (int l = 0; l < 8; l++) { x0.l[l] = sh[l][e00]; x1.l[l] = sh[l][e01]; x2.l[l] = sh[l][e10]; x3.l[l] = sh[l][e11]; }
+                for (int l = 0; l < 8; l++) { x0.l[l] = sh[l][e00]; x1.l[l] = sh[l][e01]; x2.l[l] = sh[l][e10]; x3.l[l] = sh[l][e11]; }
+            }
 #ifdef ZK_NTT_NOPAIR
             if (S > 1) { const fe t1 = tw[i2 << 1]; x1 = Fr::lmul(x1, t1); x3 = Fr::lmul(x3, t1); }
 #else
             if (S > 1) { const fe t1 = tw[i2 << 1]; Fr::lmul_pair(x1, t1, x3, t1, x1, x3); }      // stage 1: every twiddle is w^0 = 1 (uniform branch)
 #endif
             fe a0 = Fr::ladd(x0, x1), a1 = Fr::lsub(x0, x1), a2 = Fr::ladd(x2, x3), a3 = Fr::lsub(x2, x3);
+            if (S == 1) a3 = Fr::lmul(a3, tw[(size_t)1 << (logm - 2)]);                            // stages 1 and 2 of the transform: T2a = w^0 = 1 as well
+            else {
 #ifdef ZK_NTT_NOPAIR
-            a2 = Fr::lmul(a2, tw[i2]); a3 = Fr::lmul(a3, tw[i2 + ((size_t)1 << (logm - 2))]);
+                a2 = Fr::lmul(a2, tw[i2]); a3 = Fr::lmul(a3, tw[i2 + ((size_t)1 << (logm - 2))]);
 #else
-            Fr::lmul_pair(a2, tw[i2], a3, tw[i2 + ((size_t)1 << (logm - 2))], a2, a3);
+                Fr::lmul_pair(a2, tw[i2], a3, tw[i2 + ((size_t)1 << (logm - 2))], a2, a3);
 #endif
+            }
             x0 = Fr::ladd(a0, a2); x2 = Fr::lsub(a0, a2); x1 = Fr::ladd(a1, a3); x3 = Fr::lsub(a1, a3);
+            if (to_mem) { emit(gidx(e00), x0); emit(gidx(e01), x1); emit(gidx(e10), x2); emit(gidx(e11), x3); }
+            else {
 #pragma unroll
-            for (int l = 0; l < 8; l++) { sh[l][e00] = x0.l[l]; sh[l][e01] = x1.l[l]; sh[l][e10] = x2.l[l]; sh[l][e11] = x3.l[l]; }
+                for (int l = 0; l < 8; l++) { sh[l][e00] = x0.l[l]; sh[l][e01] = x1.l[l]; sh[l][e10] = x2.l[l]; sh[l][e11] = x3.l[l]; }
+            }
         }
-        __syncthreads();
+        if (!to_mem) __syncthreads();
     }
-    if (s <= k) {                                                    // an odd stage count ends with one radix-2 stage
+    if (s <= k) {                                                    // an odd stage count ends with one radix-2 stage, stored straight to memory
         const uint32_t half = 1u << (s - 1), S = s0 + s;
         for (uint32_t bf = threadIdx.x; bf < (tile >> 1); bf += blockDim.x) {
             uint32_t c = bf & (ncol - 1), q = bf >> logc;
@@ -126,21 +154,15 @@ k_ntt_pass(const fe *__restrict__ in, fe *__restrict__ out, const fe *__restrict
             // butterflies in the loose domain [0, 2p) (bn254.hpp: no conditional subtraction behind the product, sums and differences
             // fold by 2p): 25 instructions less per butterfly; the last pass normalises what it stores
             if (S > 1) v = Fr::lmul(v, tw[(size_t)j << (logm - S)]);   // stage 1: every twiddle is w^0 = 1 (uniform branch)
-            fe a = Fr::ladd(u, v), b = Fr::lsub(u, v);
-#pragma unroll
-            for (int l = 0; l < 8; l++) { sh[l][eu] = a.l[l]; sh[l][ev] = b.l[l]; }
+            emit(gidx(eu), Fr::ladd(u, v)); emit(gidx(ev), Fr::lsub(u, v));
         }
-        __syncthreads();
-    }
-    for (uint32_t e = threadIdx.x; e < tile; e += blockDim.x) {
-        uint32_t idx = base | ((e >> logc) << s0) | (e & (ncol - 1));
-        fe v;
+    } else if (k == 0) {                                             // a size-1 tile: scaling only
+        for (uint32_t e = threadIdx.x; e < tile; e += blockDim.x) {
+            fe v;
 #pragma unroll
-        for (int l = 0; l < 8; l++) v.l[l] = sh[l][e];
-        if (post) v = Fr::mul(v, post[idx]);                    // strict product: canonical whatever the (loose) input
-        else if (last_pass) v = Fr::canon(v);
-        if (fuse.sub) v = Fr::sub(v, fuse.sub[idx]);
-        out[idx] = v;
+            for (int l = 0; l < 8; l++) v.l[l] = sh[l][e];
+            emit(gidx(e), v);
+        }
     }
 }
 
