@@ -53,11 +53,16 @@ constexpr uint32_t SORT_THREADS = 256;
 constexpr uint32_t SORT_FINE_THREADS = 1024;
 constexpr uint32_t SORT_MAX_CB = 256;          // coarse bins
 constexpr uint32_t SORT_MAX_FB = 4096;         // fine buckets per coarse bin held in LDS (c <= 20)
+constexpr uint32_t SORT_STAGE = 7680;          // (bucket, payload) pairs a partition workgroup stages in LDS (60 KiB): 512 scalars x 15 windows
+static_assert(SORT_MAX_CB == SORT_THREADS, "k_sort_partition_staged: one coarse bin per thread");
 
 struct SortShape {
     uint32_t cb, fb, fine_bits, groups, per_group;   // groups = workgroups of pass 1, per_group = scalars each
-    void set(uint32_t n, uint32_t nb) {               // context creation: reads the tuning override once
-        per_group = 1024;                                   // 1024 scalars x W windows of LDS-ranked entries per workgroup
+    void set(uint32_t n, uint32_t nb, uint32_t W = 15) {   // context creation: reads the tuning override once
+        // scalars per workgroup: as many as the staged partition holds in LDS (SORT_STAGE pairs = per_group x W windows), a power of two, at most 512
+        // (512 at W = 15; 1024 with the direct scatter measured the same times)
+        per_group = 512;
+        while (per_group > 32 && (uint64_t)per_group * W > SORT_STAGE) per_group >>= 1;
         if (const char *e = getenv("ZK_SORT_PER_GROUP")) { int v = atoi(e); if (v >= 64) per_group = (uint32_t)v; }   // tuning aid
         resize(n, nb);
     }

@@ -142,6 +142,56 @@ k_sort_partition(const fe *__restrict__ scalars, const uint32_t *__restrict__ ga
     }
 }
 
+// the same scatter STAGED through LDS: a workgroup of per_group <= SORT_STAGE / W scalars ranks its entries by bin in LDS first (its
+// per-bin counts are the differences of the scanned count matrix), then copies the runs out -- consecutive lanes write consecutive pairs of one
+// bin, whole cache lines instead of one 8-byte store per lane and line (the direct scatter: 82 us per 2^20 sort, 41 us of them the stores)
+template <class C>
+__global__ void __launch_bounds__(SORT_THREADS)
+k_sort_partition_staged(const fe *__restrict__ scalars, const uint32_t *__restrict__ gather, uint32_t n, uint32_t batch, uint32_t stride, int canonical,
+                        uint32_t c, uint32_t W, SortShape ss, const uint32_t *__restrict__ counts, const uint32_t *__restrict__ bin_total,
+                        const uint32_t *__restrict__ bin_base, uint2 *__restrict__ pairs, uint32_t kbits) {
+    __shared__ uint2 stage[SORT_STAGE];
+    __shared__ uint32_t lbase[SORT_MAX_CB], lcur[SORT_MAX_CB], gpos[SORT_MAX_CB], scan[SORT_THREADS];
+    const uint32_t t = threadIdx.x, g = blockIdx.x;
+    // entries of this workgroup per bin (SORT_MAX_CB == SORT_THREADS: one bin per thread), their exclusive scan, and where bin t's run goes
+    uint32_t cnt = 0;
+    if (t < ss.cb) {
+        const uint32_t cur = counts[(size_t)t * ss.groups + g], nxt = g + 1 < ss.groups ? counts[(size_t)t * ss.groups + g + 1] : bin_total[t];
+        cnt = nxt - cur; gpos[t] = bin_base[t] + cur;
+    }
+    scan[t] = cnt;
+    __syncthreads();
+    for (uint32_t d = 1; d < SORT_THREADS; d <<= 1) {
+        const uint32_t v = t >= d ? scan[t - d] : 0;
+        __syncthreads();
+        scan[t] += v;
+        __syncthreads();
+    }
+    lbase[t] = lcur[t] = scan[t] - cnt;
+    const uint32_t local_total = scan[SORT_THREADS - 1];
+    __syncthreads();
+    const uint32_t total = n * batch, nbp = 1u << (c - 1);
+    const uint32_t i0 = g * ss.per_group, i1 = (i0 + ss.per_group < total) ? i0 + ss.per_group : total;
+    for (uint32_t i = i0 + t; i < i1; i += blockDim.x) {
+        const uint32_t pr = i / n, il = i - pr * n;
+        const fe sc = msm_load_scalar(scalars, gather, pr, stride, il, canonical);
+        uint32_t carry = 0, neg;
+        for (uint32_t w = 0; w < W; w++) {
+            uint32_t d = msm_digit(sc, w, c, carry, neg);
+            if (!d) continue;
+            const uint32_t b = pr * nbp + d - 1;                        // (proof, bucket)
+            uint2 e; e.x = (kbits ? (w << kbits) | il : w * n + il) | (neg << 31); e.y = b;     // payload as in k_sort_partition
+            stage[atomicAdd(&lcur[b >> ss.fine_bits], 1u)] = e;
+        }
+    }
+    __syncthreads();
+    for (uint32_t sl = t; sl < local_total; sl += blockDim.x) {
+        const uint2 e = stage[sl];
+        const uint32_t bin = e.y >> ss.fine_bits;
+        pairs[gpos[bin] + (sl - lbase[bin])] = e;
+    }
+}
+
 // pass 2: one workgroup per coarse bin sorts its region by fine bucket; emits off[] (nb + 1 entries) and sorted[].
 // 1024 threads per workgroup: the pass is latency-bound (two sweeps over ~60 K pairs), so it wants every wave
 // slot of the CU it runs on.
@@ -355,7 +405,7 @@ int MsmWork<C>::alloc(uint32_t n, uint32_t c, typename C::Affine *shared_table, 
     if (sort_only) { owns_table = false; table_n = n; }
     else if (shared_table) { table = shared_table; owns_table = false; table_n = n; }
     else ZK_HIP(hipMalloc(&table, sizeof(typename C::Affine) * (size_t)(n ? n : 1) * sh.W));
-    ss.set((uint32_t)(sh.n * B), (uint32_t)(sh.nb * B));            // sized for a full batch (the bins of a smaller batch are re-derived per call)
+    ss.set((uint32_t)(sh.n * B), (uint32_t)(sh.nb * B), sh.W);            // sized for a full batch (the bins of a smaller batch are re-derived per call)
     if (!sort_like) {
         ZK_HIP(hipMalloc(&pairs, sizeof(uint2) * sh.max_entries() * B));
         ZK_HIP(hipMalloc(&counts, sizeof(uint32_t) * ((size_t)SORT_MAX_CB * ss.groups + 1)));
@@ -407,6 +457,10 @@ int MsmWork<C>::enqueue_sort(const fe *scalars, const uint32_t *gather, uint32_t
     ZK_LAUNCH_SYNC(k_sort_count<C>, sq.groups, SORT_THREADS, st, scalars, gather, n, batch, stride, canonical, c, W, sq, counts);
     ZK_LAUNCH_SYNC(k_sort_colscan<C>, sq.cb, SORT_THREADS, st, counts, sq.groups, bin_total);
     ZK_LAUNCH_SYNC(k_sort_binscan<C>, 1, SORT_THREADS, st, (const uint32_t *)bin_total, sq.cb, bin_base);
+    if ((uint64_t)sq.per_group * W <= SORT_STAGE)
+        ZK_LAUNCH_SYNC(k_sort_partition_staged<C>, sq.groups, SORT_THREADS, st, scalars, gather, n, batch, stride, canonical, c, W, sq,
+                       (const uint32_t *)counts, (const uint32_t *)bin_total, (const uint32_t *)bin_base, pairs, sort_kbits);
+    else
     ZK_LAUNCH_SYNC(k_sort_partition<C>, sq.groups, SORT_THREADS, st, scalars, gather, n, batch, stride, canonical, c, W, sq,
                    (const uint32_t *)counts, (const uint32_t *)bin_base, pairs, sort_kbits);
     ZK_LAUNCH_SYNC(k_sort_fine<C>, sq.cb, SORT_FINE_THREADS, st, (const uint2 *)pairs, (const uint32_t *)bin_base, sq, nb, off, sorted);
