@@ -1462,10 +1462,18 @@ k_witness_tape(const uint32_t *__restrict__ tape, uint32_t n_records, const fe *
         if ((head >> 26) & 1u) {                                 // HINT record (zk_wplan_create_hinted): values the constraints only CHECK
             // ZK_WHINT_BITS: w[first + i] = bit i of the canonical value of w[src], i < count (field2bits-style gadgets: the bits are
             // non-deterministic advice, the constraints b (1 - b) = 0 and sum 2^i b_i = x that follow verify them)
-            const uint32_t src = target, first = inv_idx, count = out_slot;
-            const fe v = Fr::from_mont(x[src]);
+            // ZK_WHINT_INV / ZK_WHINT_NONZERO (bits 27-28 = 1 / 2): w[first] = 1 / w[src] (0 for 0: 0^(r-2) = 0), resp. [w[src] != 0] -- the M and Y of
+            // the reference's IsNonZero gadget (src/gadgets/isnonzero.cpp:48-60), whose three constraints only check them
+            const uint32_t src = target, first = inv_idx, count = out_slot, hk = (head >> 27) & 3u;
             const fe one = Fr::one(), zero = Fr::zero();
-            if (live) for (uint32_t i = 0; i < count; i++) x[first + i] = (i < 256 && ((v.l[i >> 5] >> (i & 31)) & 1u)) ? one : zero;
+            if (hk == 0) {
+                const fe v = Fr::from_mont(x[src]);
+                if (live) for (uint32_t i = 0; i < count; i++) x[first + i] = (i < 256 && ((v.l[i >> 5] >> (i & 31)) & 1u)) ? one : zero;
+            } else {
+                const fe v = x[src];
+                const fe r = hk == 1 ? Fr::inv(v) : (Fr::is_zero(v) ? zero : one);
+                if (live) x[first] = r;
+            }
             continue;
         }
         const uint32_t nA = head & 0xffu, nB = (head >> 8) & 0xffu, nC = (head >> 16) & 0xffu;
@@ -1529,7 +1537,8 @@ extern "C" int zk_wplan_create_hinted(const zk_csr *A, const zk_csr *B, const zk
     std::vector<uint32_t> hint_of((size_t)V + 1, 0xffffffffu);
     std::vector<uint8_t> hint_done(n_hints, 0);
     for (uint32_t h = 0; h < n_hints; h++) {
-        if (hints[h].kind != ZK_WHINT_BITS) return fail(ZK_ERR_ARG, "witness plan: unknown hint kind");
+        if (hints[h].kind != ZK_WHINT_BITS && hints[h].kind != ZK_WHINT_INV && hints[h].kind != ZK_WHINT_NONZERO) return fail(ZK_ERR_ARG, "witness plan: unknown hint kind");
+        if (hints[h].kind != ZK_WHINT_BITS && hints[h].count != 1) return fail(ZK_ERR_ARG, "witness plan: ZK_WHINT_INV / ZK_WHINT_NONZERO define one variable (count = 1)");
         if (hints[h].src > V || hints[h].count == 0 || (uint64_t)hints[h].first + hints[h].count > (uint64_t)V + 1 || hints[h].first == 0) return fail(ZK_ERR_ARG, "witness plan: hint variables out of range");
         for (uint32_t i = 0; i < hints[h].count; i++) {
             if (have[hints[h].first + i] || hint_of[hints[h].first + i] != 0xffffffffu) return fail(ZK_ERR_ARG, "witness plan: a hint defines a variable that is supplied or defined twice");
@@ -1541,7 +1550,7 @@ extern "C" int zk_wplan_create_hinted(const zk_csr *A, const zk_csr *B, const zk
         const uint32_t h = v <= V ? hint_of[v] : 0xffffffffu;
         if (h == 0xffffffffu || hint_done[h] || !have[hints[h].src]) return false;
         uint32_t rec[WP_WORDS] = {0};
-        rec[0] = 1u << 26; rec[1] = hints[h].src; rec[2] = hints[h].first; rec[3] = hints[h].count;
+        rec[0] = 1u << 26 | (hints[h].kind - ZK_WHINT_BITS) << 27; rec[1] = hints[h].src; rec[2] = hints[h].first; rec[3] = hints[h].count;
         tape.insert(tape.end(), rec, rec + WP_WORDS);
         for (uint32_t i = 0; i < hints[h].count; i++) have[hints[h].first + i] = 1;      // (in memory only: the first read of each goes through the cache fill)
         hint_done[h] = 1;

@@ -403,3 +403,36 @@ def field2bits_circuit(n_bits=253, value=None, seed=5):
     r1cs, w = pb.to_r1cs()
     assert pb.is_satisfied()
     return r1cs, w, (x, bits[0], n_bits)
+
+
+def isnonzero_circuit(values=(0, 5, 0, 7, 1), seed=11):
+    """The reference's IsNonZero gadget (src/gadgets/isnonzero.cpp:34-60) over a vector of private values, its results used: for every X the
+    constraints  Y (1 - Y) = 0,  X (1 - Y) = 0,  X M = Y  with the advice M = 1 / X (0 for X = 0) and Y = [X != 0] (generate_r1cs_witness,
+    :48-60), then  count = sum Y  (public),  t = count * first X,  digest = MiMC-e7 hash of (t, count).  The constraints only CHECK M and Y, and the
+    first one reads Y before anything defines it: zk_wplan needs ZK_WHINT_INV (src = X, dst = M) and ZK_WHINT_NONZERO (src = X, dst = Y).
+    Returns (R1CS, witness, [(x_var, y_var, m_var), ...])."""
+    pb = Protoboard()
+    ys = [1 if v % FR else 0 for v in values]
+    count = pb.allocate(sum(ys))
+    pb.set_input_sizes(1)
+    triples = []
+    for v, yv in zip(values, ys):
+        x = pb.allocate(v % FR)
+        y = pb.allocate(yv)
+        m = pb.allocate(pow(v % FR, FR - 2, FR))                                       # 0 for 0
+        pb.add_r1cs_constraint(V(y), lc_add(1, lc_scale(V(y), FR - 1)), 0)             # generate_boolean_r1cs_constraint(Y)
+        pb.add_r1cs_constraint(V(x), lc_add(1, lc_scale(V(y), FR - 1)), 0)             # X (1 - Y) = 0
+        pb.add_r1cs_constraint(V(x), V(m), V(y))                                       # X (1/X) = Y
+        triples.append((x, y, m))
+    pb.add_r1cs_constraint({y: 1 for _, y, _ in triples}, 1, V(count))                 # the results are used
+    t = pb.allocate(sum(ys) * (values[0] % FR) % FR)
+    pb.add_r1cs_constraint(V(count), V(triples[0][0]), V(t))
+    iv = pb.allocate(0)
+    pb.add_r1cs_constraint(V(iv), 1, 0)
+    g = MiMCe7HashGadget(pb, iv, [t, count])
+    g.generate_r1cs_witness()
+    g.generate_r1cs_constraints()
+    r1cs, w = pb.to_r1cs()
+    assert pb.is_satisfied()
+    return r1cs, w, triples
+

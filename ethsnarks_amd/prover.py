@@ -623,15 +623,17 @@ class WitnessPlan:
     """zk_wplan: the constraint system as a witness program (forward substitution), run on the GPU for k witnesses at a time.
     `known`: indices of the variables the caller supplies (ONE is implied)."""
 
-    def __init__(self, r1cs, known, device=0, bit_hints=()):
-        """bit_hints: (src, first, count) triples -- w[first + i] = bit i of w[src] (ZK_WHINT_BITS: advice the constraints only check)"""
+    def __init__(self, r1cs, known, device=0, bit_hints=(), inv_hints=(), nonzero_hints=()):
+        """bit_hints: (src, first, count) triples -- w[first + i] = bit i of w[src] (ZK_WHINT_BITS: advice the constraints only check);
+        inv_hints: (src, dst) pairs -- w[dst] = 1 / w[src], 0 for 0 (ZK_WHINT_INV); nonzero_hints: (src, dst) -- w[dst] = [w[src] != 0]
+        (ZK_WHINT_NONZERO): the M and Y of the reference's IsNonZero gadget, src/gadgets/isnonzero.cpp:48-60"""
         lib = load_library(_lib_path_loaded)
         flags = np.zeros(r1cs.V + 1, dtype=np.uint8)
         flags[np.asarray(list(known), dtype=np.int64)] = 1
         keep = []
         a, b, c = _csr_structs(r1cs, keep)
         h = C.c_void_p()
-        hints = np.asarray([[1, s_, f_, n_] for s_, f_, n_ in bit_hints], dtype=np.uint32).reshape(-1, 4)
+        hints = np.asarray([[1, s_, f_, n_] for s_, f_, n_ in bit_hints] + [[2, s_, d_, 1] for s_, d_ in inv_hints] + [[3, s_, d_, 1] for s_, d_ in nonzero_hints], dtype=np.uint32).reshape(-1, 4)
         _check(lib.zk_wplan_create_hinted(C.byref(a), C.byref(b), C.byref(c), C.c_uint32(r1cs.nC), C.c_uint32(r1cs.V),
                                           flags.ctypes.data_as(C.POINTER(C.c_uint8)),
                                           hints.ctypes.data_as(C.c_void_p) if len(hints) else None, C.c_uint32(len(hints)), device, C.byref(h)))

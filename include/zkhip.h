@@ -271,9 +271,13 @@ bool ethsnarks_verify(const char *vk_json, const char *proof_json);
  * zk_dev_*: device-memory helpers for hosts without a HIP binding of their own. */
 int zk_wplan_create(const zk_csr *A, const zk_csr *B, const zk_csr *C, uint32_t nC, uint32_t V, const uint8_t *known, int device, zk_wplan **out);
 /* ... with HINTS for values the constraints only check (gadgets with non-deterministic advice, e.g. src/gadgets/field2bits_strict.cpp):
- *   ZK_WHINT_BITS   w[first + i] = bit i of the canonical value of w[src], i < count
+ *   ZK_WHINT_BITS      w[first + i] = bit i of the canonical value of w[src], i < count
+ *   ZK_WHINT_INV       w[first] = 1 / w[src], 0 when w[src] = 0            (count = 1; src/gadgets/isnonzero.cpp: M)
+ *   ZK_WHINT_NONZERO   w[first] = 1 when w[src] != 0, else 0               (count = 1; src/gadgets/isnonzero.cpp: Y)
  * A hint runs right before the first constraint that reads one of its variables (its source must be known by then). */
 #define ZK_WHINT_BITS 1
+#define ZK_WHINT_INV 2
+#define ZK_WHINT_NONZERO 3
 typedef struct { uint32_t kind, src, first, count; } zk_whint;
 int zk_wplan_create_hinted(const zk_csr *A, const zk_csr *B, const zk_csr *C, uint32_t nC, uint32_t V, const uint8_t *known,
                            const zk_whint *hints, uint32_t n_hints, int device, zk_wplan **out);

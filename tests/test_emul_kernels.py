@@ -360,3 +360,36 @@ def test_witness_plan_with_bit_decomposition_hints(zk, oracle):
     for p in range(k):
         assert zk.proof_to_json(ctx.prove_combine(parts[p]), got[p][1:2]) == oracle.prove(pk_o, r, got[p])[0]
     ctx.close(); plan.close(); buf.free()
+
+
+def test_witness_plan_with_inverse_and_nonzero_hints(zk, oracle):
+    """The reference's IsNonZero gadget (src/gadgets/isnonzero.cpp): M = 1 / X (0 for 0) and Y = [X != 0] are advice that its three
+    constraints only check, and the first of them reads Y before anything defines it.  ZK_WHINT_INV / ZK_WHINT_NONZERO supply both: the plan
+    completes the witness from the X alone (zero and non-zero values), equal to the front end's; a wrong hint set is refused or caught."""
+    from ethsnarks_amd import gadgets as G
+    vals = [(0, 5, 0, 7, 1), (3, 0, 0, 0, 9), (0, 0, 0, 0, 0)]
+    cases = [G.isnonzero_circuit(v) for v in vals]
+    r, triples = cases[0][0], cases[0][2]
+    iv = max(max(t) for t in triples) + 2                            # allocation order: count, (x, y, m)*, t, iv, ...
+    supplied = [0] + [x for x, _, _ in triples] + [iv]
+    with pytest.raises(zk.ZkError) as e:
+        zk.WitnessPlan(r, supplied)
+    assert "solved order" in str(e.value)
+    plan = zk.WitnessPlan(r, supplied, inv_hints=[(x, m) for x, _, m in triples], nonzero_hints=[(x, y) for x, y, _ in triples])
+    k = len(cases)
+    start = np.zeros((k, r.V + 1, 4), dtype=np.uint64)
+    for p in range(k):
+        start[p, supplied] = F.fr_to_mont([cases[p][1][i] for i in supplied])
+    buf = zk.DeviceBuffer(32 * (r.V + 1) * k)
+    buf.upload(start)
+    assert plan.solve(buf.ptr, k) == 0
+    got = buf.download((k, r.V + 1, 4))
+    for p in range(k):
+        assert np.array_equal(got[p], F.fr_to_mont(cases[p][1]))
+    plan.close()
+    # the hints exchanged (Y from the inverse, M from the flag): the checks catch it wherever X is neither 0 nor 1
+    bad = zk.WitnessPlan(r, supplied, inv_hints=[(x, y) for x, y, _ in triples], nonzero_hints=[(x, m) for x, _, m in triples])
+    buf.upload(start)
+    assert bad.solve(buf.ptr, k) > 0
+    bad.close(); buf.free()
+

@@ -350,6 +350,39 @@ def test_witness_plan_with_bit_decomposition_hints(hip, oracle):
     ctx.close(); plan.close(); buf.free()
 
 
+def test_witness_plan_with_inverse_and_nonzero_hints(hip, oracle):
+    """The reference's IsNonZero gadget (src/gadgets/isnonzero.cpp:34-60): M = 1 / X (0 for 0) and Y = [X != 0] are advice its constraints only
+    check (the first reads Y before anything defines it).  ZK_WHINT_INV / ZK_WHINT_NONZERO complete the witnesses on the GPU from the X alone;
+    proofs of the completed witnesses equal the oracle's."""
+    from ethsnarks_amd import gadgets as G
+    vals = [(0, 5, 0, 7, 1), (3, 0, 0, 0, 9), (0, 0, 0, 0, 0), (1, 2, 3, 4, 5)]
+    cases = [G.isnonzero_circuit(v) for v in vals]
+    r, triples = cases[0][0], cases[0][2]
+    iv = max(max(t) for t in triples) + 2                            # allocation order: count, (x, y, m)*, t, iv, ...
+    supplied = [0] + [x for x, _, _ in triples] + [iv]
+    with pytest.raises(hip.ZkError):
+        hip.WitnessPlan(r, supplied)                                 # not in solved order without the hints
+    plan = hip.WitnessPlan(r, supplied, inv_hints=[(x, m) for x, _, m in triples], nonzero_hints=[(x, y) for x, y, _ in triples])
+    k = len(cases)
+    start = np.zeros((k, r.V + 1, 4), dtype=np.uint64)
+    for p in range(k):
+        start[p, supplied] = F.fr_to_mont([cases[p][1][i] for i in supplied])
+    buf = hip.DeviceBuffer(32 * (r.V + 1) * k)
+    buf.upload(start)
+    assert plan.solve(buf.ptr, k) == 0
+    got = buf.download((k, r.V + 1, 4))
+    for p in range(k):
+        assert np.array_equal(got[p], F.fr_to_mont(cases[p][1]))
+    pk, _ = hip.keygen(r, seed=33)
+    pk_o = oracle.pk_from_parts(pk.parts())
+    ctx = hip.ProverContext(pk, r, max_batch=k)
+    ctx.submit_batch(None, device_ptr=buf.ptr, k=k)
+    parts, _ = ctx.collect_batch(k)
+    for p in range(k):
+        assert hip.proof_to_json(ctx.prove_combine(parts[p]), got[p][1:2]) == oracle.prove(pk_o, r, got[p])[0]
+    ctx.close(); plan.close(); buf.free()
+
+
 def test_prove_batch_chain_shared_sort_and_odd_batch(hip, oracle):
     """dense queries (A-, B-, L-query on one shared witness sort), a batch that is not a power of two, the asynchronous form"""
     r, _ = R.synthetic_chain((1 << 12) - 2, 1)
