@@ -34,7 +34,7 @@ namespace zk { bool exp_skip(const char *name); }
 // error codes of the C ABI (include/zkhip.h)
 enum {
     ZK_OK = 0, ZK_ERR_ARG = 1, ZK_ERR_IO = 2, ZK_ERR_FORMAT = 3, ZK_ERR_HIP = 4, ZK_ERR_NOMEM = 5,
-    ZK_ERR_SHAPE = 6, ZK_ERR_DEGREE = 7, ZK_ERR_NODEVICE = 8, ZK_ERR_BUFFER = 9
+    ZK_ERR_SHAPE = 6, ZK_ERR_DEGREE = 7, ZK_ERR_NODEVICE = 8, ZK_ERR_BUFFER = 9, ZK_ERR_INTERNAL = 10
 };
 
 namespace zk {
@@ -45,6 +45,14 @@ inline int hip_fail(hipError_t e, const char *what, const char *file, int line) 
 }
 inline int fail_msg(int code, const char *msg) { snprintf(g_last_error, sizeof(g_last_error), "%s", msg); return code; }
 }  // namespace zk
+// Exception barrier of the C ABI ("returns int codes, never throws / aborts").  Every extern "C" entry point is a
+// function-try-block that ends in one of these handlers: the host side uses std::vector / std::string / std::mutex, so an allocation
+// failure (a key header that declares 2^28 points, a 2^28-row CSR on a small host) must come back as ZK_ERR_NOMEM, anything else as
+// ZK_ERR_INTERNAL with the exception's text in zk_last_error() -- never as std::terminate in the caller's process.
+namespace zk { int on_exception() noexcept; }
+#define ZK_GUARD catch (...) { return zk::on_exception(); }
+#define ZK_GUARD_VOID catch (...) { (void)zk::on_exception(); }
+#define ZK_GUARD_BOOL catch (...) { (void)zk::on_exception(); return false; }
 #define ZK_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return zk::hip_fail(e_, #call, __FILE__, __LINE__); } while (0)
 #define ZK_TRY(call) do { int rc_ = (call); if (rc_ != ZK_OK) return rc_; } while (0)
 

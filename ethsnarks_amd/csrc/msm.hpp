@@ -214,7 +214,13 @@ struct MsmWork {
     int enqueue_sort(const fe *scalars, const uint32_t *gather, uint32_t n, int canonical, hipStream_t st, uint32_t batch = 1, uint32_t stride = 0);
     // tail_lanes: lanes per logical thread of the bucket-reduction kernels for this call (0 = the shape's choice, sh.quad)
     int enqueue_reduce(const SortView &v, hipStream_t st, hipStream_t st_tail, uint32_t tail_lanes = 0);
-    template <int Q> int launch_reduce(uint32_t K, uint32_t groups, hipStream_t st);
+    // ... and enqueue_reduce's own halves: the accumulation (chunk pieces) on st, the bucket reduction on st_tail.  `also`: another
+    // MsmWork whose pending chunk pieces (same buckets, same batch) are folded into THIS reduction, so two multi-exponentiations
+    // whose results are only ever added -- C = Ht + Lt, tcc:540 -- share one tail
+    int enqueue_accumulate(const SortView &v, hipStream_t st);
+    int enqueue_tail(hipStream_t st_tail, uint32_t tail_lanes = 0, MsmWork *also = nullptr);
+    bool tail_pending = false;                  // an accumulation whose chunk pieces no tail has consumed yet
+    template <int Q> int launch_reduce(uint32_t K, uint32_t groups, hipStream_t st, const MsmWork *also);
     uint32_t tree_levels(uint32_t groups, uint32_t lanes) const;
     const uint32_t *cur_off = nullptr;          // bucket offsets of the sort driving the current reduction
     uint32_t sort_batch = 1;                    // batch of the last enqueue_sort

@@ -4,6 +4,7 @@
 // not depend on the curve are still templated on it so that each translation unit owns its symbols.
 #pragma once
 #include "msm.hpp"
+#include <string.h>
 
 namespace zk {
 
@@ -317,20 +318,32 @@ k_msm_accumulate(const typename C::Affine *__restrict__ table, const uint32_t *_
 // thread / quad per bucket: sum its chunk pieces (serial; buckets over MSM_HEAVY pieces are queued).
 // The bucket-reduction tails are chains of dependent group operations run by few waves: their launch bounds ask for
 // registers (no scratch), not for occupancy.
+// the chunk pieces of bucket b under one sort: [s0, s1) (empty bucket: s0 == s1)
+struct PieceRange { uint32_t s0, s1; ZK_HD uint32_t n() const { return s1 - s0; } };
+static ZK_D PieceRange msm_piece_range(const uint32_t *__restrict__ off, uint32_t nb, const ChunkRule &rule, uint32_t b) {
+    const uint32_t e0 = off[b], e1 = off[b + 1], seg = rule.len(off[nb]);
+    PieceRange r; r.s0 = r.s1 = 0;
+    if (e1 > e0) { r.s0 = e0 / seg + b; r.s1 = (e1 - 1) / seg + b + 1; }
+    return r;
+}
+// piece2 != nullptr: a SECOND accumulation over the same bucket ids (another sort: off2, rule2) whose pieces are folded into the same
+// bucket sums -- the H- and the L-query only ever meet as C = Ht + Lt (tcc:540), so ONE bucket reduction serves both (MsmWork::enqueue_tail)
 template <class C, int Q>
 __global__ void __launch_bounds__(64, C::WAVES_PER_SIMD / 2)
 k_msm_bucket_finalize(const typename C::XYZZ *__restrict__ piece, const uint32_t *__restrict__ off,
-                      uint32_t nb, ChunkRule rule, typename C::XYZZ *__restrict__ bucket,
+                      uint32_t nb, ChunkRule rule,
+                      const typename C::XYZZ *__restrict__ piece2, const uint32_t *__restrict__ off2, ChunkRule rule2,
+                      typename C::XYZZ *__restrict__ bucket,
                       uint32_t *__restrict__ heavy_list, uint32_t *__restrict__ heavy_count) {
     const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x, b = gt / Q, ql = gt % Q;
     if (b >= nb) return;
-    const uint32_t e0 = off[b], e1 = off[b + 1], seg = rule.len(off[nb]);
+    const PieceRange r1 = msm_piece_range(off, nb, rule, b);
+    PieceRange r2; r2.s0 = r2.s1 = 0;
+    if (piece2) r2 = msm_piece_range(off2, nb, rule2, b);
+    if (r1.n() + r2.n() > MSM_HEAVY) { if (ql == 0) heavy_list[atomicAdd(heavy_count, 1u)] = b; return; }
     typename C::XYZZ acc = C::infinity();
-    if (e1 > e0) {
-        const uint32_t s0 = e0 / seg + b, s1 = (e1 - 1) / seg + b + 1;
-        if (s1 - s0 > MSM_HEAVY) { if (ql == 0) heavy_list[atomicAdd(heavy_count, 1u)] = b; return; }
-        for (uint32_t s = s0; s < s1; s++) acc = C::template addQ<Q>(acc, piece[s], ql);
-    }
+    for (uint32_t s = r1.s0; s < r1.s1; s++) acc = C::template addQ<Q>(acc, piece[s], ql);
+    for (uint32_t s = r2.s0; s < r2.s1; s++) acc = C::template addQ<Q>(acc, piece2[s], ql);
     if (ql == 0) bucket[b] = acc;
 }
 
@@ -339,14 +352,19 @@ k_msm_bucket_finalize(const typename C::XYZZ *__restrict__ piece, const uint32_t
 template <class C, int Q>
 __global__ void __launch_bounds__(128 * Q)
 k_msm_heavy(const typename C::XYZZ *__restrict__ piece, const uint32_t *__restrict__ off, uint32_t nb, ChunkRule rule,
+            const typename C::XYZZ *__restrict__ piece2, const uint32_t *__restrict__ off2, ChunkRule rule2,
             const uint32_t *__restrict__ heavy_list, const uint32_t *__restrict__ heavy_count,
             typename C::XYZZ *__restrict__ bucket) {
     __shared__ typename C::XYZZ sh[64];
-    const uint32_t nheavy = *heavy_count, lt = threadIdx.x / Q, ql = threadIdx.x % Q, seg = rule.len(off[nb]);
+    const uint32_t nheavy = *heavy_count, lt = threadIdx.x / Q, ql = threadIdx.x % Q;
     for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
-        const uint32_t b = heavy_list[h], s0 = off[b] / seg + b, s1 = (off[b + 1] - 1) / seg + b + 1;
+        const uint32_t b = heavy_list[h];
+        const PieceRange r1 = msm_piece_range(off, nb, rule, b);
+        PieceRange r2; r2.s0 = r2.s1 = 0;
+        if (piece2) r2 = msm_piece_range(off2, nb, rule2, b);
         typename C::XYZZ acc = C::infinity();
-        for (uint32_t s = s0 + lt; s < s1; s += 128) acc = C::template addQ<Q>(acc, piece[s], ql);
+        for (uint32_t i = lt; i < r1.n() + r2.n(); i += 128)         // the two runs of pieces, one after the other
+            acc = C::template addQ<Q>(acc, i < r1.n() ? piece[r1.s0 + i] : piece2[r2.s0 + (i - r1.n())], ql);
         for (uint32_t half = 64; half > 0; half >>= 1) {
             if (lt >= half && lt < 2 * half && ql == 0) sh[lt - half] = acc;
             __syncthreads();
@@ -479,11 +497,15 @@ uint32_t MsmWork<C>::tree_levels(uint32_t groups, uint32_t lanes) const {
 // bucket reduction with Q lanes per logical thread
 template <class C>
 template <int Q>
-int MsmWork<C>::launch_reduce(uint32_t K, uint32_t groups, hipStream_t st) {      // groups: per proof
+int MsmWork<C>::launch_reduce(uint32_t K, uint32_t groups, hipStream_t st, const MsmWork<C> *also) {      // groups: per proof
     const uint32_t nb = sh.nb * cur_batch, all_groups = groups * cur_batch;
-    ZK_LAUNCH((k_msm_bucket_finalize<C, Q>), zk_div_up((uint64_t)nb * Q, 64), 64, st, (const typename C::XYZZ *)pieces, (const uint32_t *)cur_off, nb, sh.chunk, bucket, heavy_list, heavy_count);
+    const typename C::XYZZ *piece2 = also ? also->pieces : nullptr;
+    const uint32_t *off2 = also ? also->cur_off : nullptr;
+    const ChunkRule rule2 = also ? also->sh.chunk : sh.chunk;
+    ZK_LAUNCH((k_msm_bucket_finalize<C, Q>), zk_div_up((uint64_t)nb * Q, 64), 64, st, (const typename C::XYZZ *)pieces, (const uint32_t *)cur_off, nb, sh.chunk,
+              piece2, off2, rule2, bucket, heavy_list, heavy_count);
     ZK_LAUNCH_SYNC((k_msm_heavy<C, Q>), MSM_HEAVY_GRID, 128 * Q, st, (const typename C::XYZZ *)pieces, (const uint32_t *)cur_off, nb, sh.chunk,
-                   (const uint32_t *)heavy_list, (const uint32_t *)heavy_count, bucket);
+                   piece2, off2, rule2, (const uint32_t *)heavy_list, (const uint32_t *)heavy_count, bucket);
     ZK_LAUNCH((k_msm_group_reduce<C, Q>), zk_div_up((uint64_t)all_groups * Q, 64), 64, st, (const typename C::XYZZ *)bucket, nb, K, groups, partial_a);
     typename C::XYZZ *cur = partial_a, *nxt = partial_b;
     uint32_t count = groups;
@@ -496,13 +518,12 @@ int MsmWork<C>::launch_reduce(uint32_t K, uint32_t groups, hipStream_t st) {    
     return ZK_OK;
 }
 
+// first half of the reduction: the machine-filling accumulation of the sorted entries into chunk pieces, on `st`
 template <class C>
-int MsmWork<C>::enqueue_reduce(const SortView &v, hipStream_t st, hipStream_t st_tail, uint32_t tail_lanes) {
+int MsmWork<C>::enqueue_accumulate(const SortView &v, hipStream_t st) {
     if (!v.sorted || !v.batch || v.batch > max_batch || v.nb != sh.nb * v.batch) return fail_msg(ZK_ERR_ARG, "MSM reduce: the driving sort has a different bucket count");   // a borrowed sort must have this MSM's buckets
     cur_batch = v.batch;
     const uint32_t nb = v.nb;                                   // buckets of all proofs of the batch
-    const uint32_t G0 = sh.group, K = sh.nb < G0 ? sh.nb : G0, groups = sh.nb / K;   // running-sum groups per proof
-    ZK_HIP(hipMemsetAsync(heavy_count, 0, sizeof(uint32_t), st));
     // the entry count is only known on the device: launch for the most chunks it can give, threads past the end exit
     const uint64_t max_seg = sh.chunk.max_chunks(v.entries_bound);
     if (max_seg + nb + 1 > sh.chunk.max_chunks(sh.max_entries() * max_batch) + (uint64_t)sh.nb * max_batch + 1) return fail_msg(ZK_ERR_ARG, "MSM reduce: the driving sort has more entries than this MSM was allocated for");
@@ -520,10 +541,31 @@ int MsmWork<C>::enqueue_reduce(const SortView &v, hipStream_t st, hipStream_t st
         ZK_LAUNCH((k_msm_accumulate<C, 1>), zk_div_up(max_seg, 64), 64, st, (const typename C::Affine *)table, v.sorted, v.off,
                   nb, sh.chunk, v.remap_src, v.remap_offset, v.remap_pos, table_n, v.remap_kbits, pieces);
     ZK_HIP(hipEventRecord(ev_acc1, st));
-    if (st_tail != st) { ZK_HIP(hipStreamWaitEvent(st_tail, ev_acc1, 0)); st = st_tail; }
     cur_off = v.off;
+    tail_pending = true;
+    return ZK_OK;
+}
+
+// second half: chunk pieces -> bucket sums -> sum_b (b + 1) B_b -> one point per proof, on st_tail (behind this MSM's accumulation).
+// also != nullptr: the chunk pieces of ANOTHER accumulation over the same bucket ids (same window bits, same batch; its accumulation
+// queued earlier on the same accumulation stream) are folded into this MSM's buckets -- the result is the SUM of both multi-
+// exponentiations, and `also` contributes the point at infinity from then on (its host_result is cleared here).
+template <class C>
+int MsmWork<C>::enqueue_tail(hipStream_t st_tail, uint32_t tail_lanes, MsmWork<C> *also) {
+    if (!tail_pending) return fail_msg(ZK_ERR_ARG, "MSM tail: no accumulation is pending");
+    if (also && (!also->tail_pending || also->sh.nb != sh.nb || also->cur_batch != cur_batch)) return fail_msg(ZK_ERR_ARG, "MSM tail: the accumulation to fold in has other buckets or another batch");
+    tail_pending = false;
+    const uint32_t G0 = sh.group, K = sh.nb < G0 ? sh.nb : G0, groups = sh.nb / K;   // running-sum groups per proof
+    hipStream_t st = st_tail;
+    ZK_HIP(hipStreamWaitEvent(st, ev_acc1, 0));
+    if (also) {
+        also->tail_pending = false;
+        ZK_HIP(hipStreamWaitEvent(st, also->ev_acc1, 0));
+        memset(also->host_result, 0, sizeof(typename C::XYZZ) * also->max_batch);        // infinity (ZZ = 0): its share is inside this MSM's result
+    }
+    ZK_HIP(hipMemsetAsync(heavy_count, 0, sizeof(uint32_t), st));
     const uint32_t lanes = tail_lanes == 4 || tail_lanes == 1 ? tail_lanes : sh.quad;
-    const int rc = lanes == 4 ? launch_reduce<4>(K, groups, st) : launch_reduce<1>(K, groups, st);
+    const int rc = lanes == 4 ? launch_reduce<4>(K, groups, st, also) : launch_reduce<1>(K, groups, st, also);
     if (rc != ZK_OK) return rc;
     typename C::XYZZ *cur = (tree_levels(groups, lanes) & 1) ? partial_b : partial_a;
     ZK_HIP(hipGetLastError());
@@ -533,6 +575,12 @@ int MsmWork<C>::enqueue_reduce(const SortView &v, hipStream_t st, hipStream_t st
         else ZK_HIP(hipMemcpy2DAsync(dev_result, dev_result_pitch, cur, sizeof(typename C::XYZZ), sizeof(typename C::XYZZ), cur_batch, hipMemcpyDeviceToDevice, st));
     }
     return ZK_OK;
+}
+
+template <class C>
+int MsmWork<C>::enqueue_reduce(const SortView &v, hipStream_t st, hipStream_t st_tail, uint32_t tail_lanes) {
+    ZK_TRY(enqueue_accumulate(v, st));
+    return enqueue_tail(st_tail ? st_tail : st, tail_lanes, nullptr);
 }
 
 template <class C>

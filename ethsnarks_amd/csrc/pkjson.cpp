@@ -113,15 +113,15 @@ template <class F, class E, class J, class A> void normalise(const std::vector<J
 }
 }  // namespace
 
-extern "C" int zk_pk_from_bellman_json(const char *path, zk_pk **out) {
+extern "C" int zk_pk_from_bellman_json(const char *path, zk_pk **out) try {
     if (!path || !out) return jfail(ZK_ERR_ARG, "null argument");
     std::string js;
     {
-        FILE *f = fopen(path, "rb");
+        struct Closer { FILE *f; ~Closer() { if (f) fclose(f); } } fc{fopen(path, "rb")};
+        FILE *f = fc.f;
         if (!f) return jfail(ZK_ERR_IO, std::string("cannot open ") + path);
         char buf[1 << 16]; size_t k;
         while ((k = fread(buf, 1, sizeof(buf), f)) > 0) js.append(buf, k);
-        fclose(f);
     }
     std::vector<JacG1> A, B1, Cq, Hq, one;
     std::vector<JacG2> B2, two;
@@ -154,14 +154,14 @@ extern "C" int zk_pk_from_bellman_json(const char *path, zk_pk **out) {
                             (uint32_t)A.size(), (uint32_t)a_idx.size(), a_idx.data(), (const uint64_t *)a_val.data(),
                             (uint32_t)A.size(), (uint32_t)b_idx.size(), b_idx.data(), (const uint64_t *)b_val.data(),
                             (uint32_t)H.size(), (const uint64_t *)H.data(), (uint32_t)L.size(), (const uint64_t *)L.data(), out);
-}
+} ZK_GUARD
 
 // pk_bellman2ethsnarks (src/export.cpp:267-328): JSON in, nozk `.raw` out
-extern "C" int zk_pk_bellman2ethsnarks(const char *bellman_pk_json, const char *pk_raw) {
+extern "C" int zk_pk_bellman2ethsnarks(const char *bellman_pk_json, const char *pk_raw) try {
     zk_pk *pk = nullptr;
     int rc = zk_pk_from_bellman_json(bellman_pk_json, &pk);
     if (rc != ZK_OK) return rc;
     rc = zk_pk_save_raw(pk, pk_raw, ZK_CODEC_ALT_BN128);
     zk_pk_free(pk);
     return rc;
-}
+} ZK_GUARD

@@ -9,6 +9,7 @@
 // Pairing: optimal ate on BN254, computed the plain way -- Fq12 = Fq[w]/(w^12 - 18 w^6 + 82), affine
 // Miller loop over the twist, final exponentiation by the full (q^12 - 1)/r -- because verification is
 // off the proving path; it is here to close the keygen -> prove -> verify loop without py_ecc or an EVM.
+#include <memory>
 #include <string>
 #include <vector>
 #include <string.h>
@@ -232,16 +233,15 @@ bool parse_proof(const std::string &pf, G1::Affine &A, G2::Affine &B, G1::Affine
 }
 }  // namespace
 
-extern "C" int zk_vk_from_json(const char *vk_json, zk_vk **out) {
+extern "C" int zk_vk_from_json(const char *vk_json, zk_vk **out) try {
     if (!vk_json || !out) return vfail(ZK_ERR_ARG, "null argument");
-    zk_vk *vk = new (std::nothrow) zk_vk();
-    if (!vk) return ZK_ERR_NOMEM;
-    if (!parse_vk(vk_json, *vk)) { delete vk; return vfail(ZK_ERR_FORMAT, "cannot parse verification key JSON"); }
-    *out = vk;
+    std::unique_ptr<zk_vk> vk(new zk_vk());
+    if (!parse_vk(vk_json, *vk)) return vfail(ZK_ERR_FORMAT, "cannot parse verification key JSON");
+    *out = vk.release();
     return ZK_OK;
-}
+} ZK_GUARD
 
-extern "C" int zk_proof_from_json(const char *proof_json, zk_proof *out, uint64_t *inputs_canon, uint32_t cap, uint32_t *n_inputs) {
+extern "C" int zk_proof_from_json(const char *proof_json, zk_proof *out, uint64_t *inputs_canon, uint32_t cap, uint32_t *n_inputs) try {
     if (!proof_json || !out || !n_inputs) return vfail(ZK_ERR_ARG, "null argument");
     G1::Affine A, Cc; G2::Affine B; std::vector<fe> in;
     if (!parse_proof(proof_json, A, B, Cc, in)) return vfail(ZK_ERR_FORMAT, "cannot parse proof JSON");
@@ -254,9 +254,9 @@ extern "C" int zk_proof_from_json(const char *proof_json, zk_proof *out, uint64_
     if (in.size() > cap || (in.size() && !inputs_canon)) return vfail(ZK_ERR_BUFFER, "input buffer too small");
     for (size_t i = 0; i < in.size(); i++) memcpy(inputs_canon + 4 * i, in[i].l, 32);
     return ZK_OK;
-}
+} ZK_GUARD
 
-extern "C" int zk_verify(const char *vk_json, const char *proof_json, int *accepted) {
+extern "C" int zk_verify(const char *vk_json, const char *proof_json, int *accepted) try {
     if (!vk_json || !proof_json || !accepted) return vfail(ZK_ERR_ARG, "null argument");
     *accepted = 0;
     zk_vk key;
@@ -282,10 +282,10 @@ extern "C" int zk_verify(const char *vk_json, const char *proof_json, int *accep
     f = f12_mul(f, miller_loop(delta, G1::neg(Cc)));
     *accepted = f12_is_one(final_exp(f)) ? 1 : 0;
     return ZK_OK;
-}
+} ZK_GUARD
 
 // drop-in for libethsnarks_verify (src/verify_dll.cpp:3-10): true iff the proof verifies
-extern "C" bool ethsnarks_verify(const char *vk_json, const char *proof_json) {
+extern "C" bool ethsnarks_verify(const char *vk_json, const char *proof_json) try {
     int ok = 0;
     return zk_verify(vk_json, proof_json, &ok) == ZK_OK && ok == 1;
-}
+} ZK_GUARD_BOOL

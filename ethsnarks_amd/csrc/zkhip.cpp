@@ -6,13 +6,17 @@
 // around the kernels of ntt.hpp / msm.hpp.  No CPU compute path exists in this library.
 #include <algorithm>
 #include <atomic>
+#include <memory>
 #include <mutex>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 #include <chrono>
 #include <string.h>
 #include <stddef.h>
 #include <stdlib.h>
+#include <sys/stat.h>
 
 #include "common.hpp"
 #include "bn254.hpp"
@@ -23,6 +27,15 @@
 
 namespace zk { thread_local char g_last_error[256] = ""; }
 using namespace zk;
+
+// the handler every extern "C" entry point ends in (common.hpp ZK_GUARD): called inside a catch (...) block
+int zk::on_exception() noexcept {
+    try { throw; }
+    catch (const std::bad_alloc &) { return fail_msg(ZK_ERR_NOMEM, "out of host memory (std::bad_alloc)"); }
+    catch (const std::length_error &e) { snprintf(g_last_error, sizeof(g_last_error), "out of host memory (std::length_error: %s)", e.what()); return ZK_ERR_NOMEM; }
+    catch (const std::exception &e) { snprintf(g_last_error, sizeof(g_last_error), "internal error: %s", e.what()); return ZK_ERR_INTERNAL; }
+    catch (...) { return fail_msg(ZK_ERR_INTERNAL, "internal error: unknown exception"); }
+}
 
 // ---- launch accounting (common.hpp: ZK_LAUNCH)
 #ifndef ZK_EMUL
@@ -61,14 +74,14 @@ bool zk::exp_skip(const char *name) {
     return false;
 }
 #endif
-extern "C" int zk_profile_begin(void) {
+extern "C" int zk_profile_begin(void) try {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     for (auto &r : g_prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
     g_prof.clear();
     g_prof_on = true;
     return ZK_OK;
-}
-extern "C" int zk_profile_end(float *kernel_ms_sum, uint32_t *launches, char *buf, size_t cap) {
+} ZK_GUARD
+extern "C" int zk_profile_end(float *kernel_ms_sum, uint32_t *launches, char *buf, size_t cap) try {
     g_prof_on = false;
     if (hipDeviceSynchronize() != hipSuccess) return fail_msg(ZK_ERR_HIP, "hipDeviceSynchronize failed");
     std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -93,26 +106,26 @@ extern "C" int zk_profile_end(float *kernel_ms_sum, uint32_t *launches, char *bu
         snprintf(buf, cap, "%s", s.c_str());
     }
     return ZK_OK;
-}
-extern "C" int zk_device_info(int device, uint32_t *compute_units, uint32_t *clock_mhz, char *name, size_t name_cap) {
+} ZK_GUARD
+extern "C" int zk_device_info(int device, uint32_t *compute_units, uint32_t *clock_mhz, char *name, size_t name_cap) try {
     hipDeviceProp_t p;
     if (hipGetDeviceProperties(&p, device) != hipSuccess) return fail_msg(ZK_ERR_NODEVICE, "hipGetDeviceProperties failed: no usable HIP device");
     if (compute_units) *compute_units = (uint32_t)p.multiProcessorCount;
     if (clock_mhz) *clock_mhz = (uint32_t)(p.clockRate / 1000);
     if (name && name_cap) snprintf(name, name_cap, "%s", p.name);
     return ZK_OK;
-}
-extern "C" int zk_device_pci_bus_id(int device, char *buf, size_t cap) {
+} ZK_GUARD
+extern "C" int zk_device_pci_bus_id(int device, char *buf, size_t cap) try {
     if (!buf || cap < 16) return fail_msg(ZK_ERR_ARG, "buffer too small");
     if (hipDeviceGetPCIBusId(buf, (int)cap, device) != hipSuccess) return fail_msg(ZK_ERR_NODEVICE, "hipDeviceGetPCIBusId failed: no usable HIP device");
     return ZK_OK;
-}
+} ZK_GUARD
 #else
-extern "C" int zk_device_pci_bus_id(int, char *buf, size_t cap) { if (buf && cap) snprintf(buf, cap, "emulation"); return ZK_OK; }
+extern "C" int zk_device_pci_bus_id(int, char *buf, size_t cap) try { if (buf && cap) snprintf(buf, cap, "emulation"); return ZK_OK; } ZK_GUARD
 extern "C" uint64_t zk_launch_count(void) { return 0; }
-extern "C" int zk_profile_begin(void) { return ZK_OK; }
-extern "C" int zk_profile_end(float *s, uint32_t *n, char *buf, size_t cap) { if (s) *s = 0; if (n) *n = 0; if (buf && cap) buf[0] = 0; return ZK_OK; }
-extern "C" int zk_device_info(int, uint32_t *cu, uint32_t *mhz, char *name, size_t cap) { if (cu) *cu = 1; if (mhz) *mhz = 0; if (name && cap) snprintf(name, cap, "emulation"); return ZK_OK; }
+extern "C" int zk_profile_begin(void) try { return ZK_OK; } ZK_GUARD
+extern "C" int zk_profile_end(float *s, uint32_t *n, char *buf, size_t cap) try { if (s) *s = 0; if (n) *n = 0; if (buf && cap) buf[0] = 0; return ZK_OK; } ZK_GUARD
+extern "C" int zk_device_info(int, uint32_t *cu, uint32_t *mhz, char *name, size_t cap) try { if (cu) *cu = 1; if (mhz) *mhz = 0; if (name && cap) snprintf(name, cap, "emulation"); return ZK_OK; } ZK_GUARD
 #endif
 
 static int fail(int code, const char *msg) { return fail_msg(code, msg); }
@@ -143,18 +156,30 @@ extern "C" const char *zk_strerror(int code) {
     case ZK_ERR_DEGREE: return "H polynomial has wrong degree (witness does not satisfy the R1CS)";
     case ZK_ERR_NODEVICE: return "no HIP device";
     case ZK_ERR_BUFFER: return "output buffer too small";
+    case ZK_ERR_INTERNAL: return "internal error (exception caught at the C ABI)";
     default: return "unknown error";
     }
 }
 extern "C" const char *zk_last_error(void) { return g_last_error; }
-extern "C" int zk_device_count(int *count) {
+extern "C" int zk_device_count(int *count) try {
     if (!count) return ZK_ERR_ARG;
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess) { *count = 0; return fail(ZK_ERR_NODEVICE, "hipGetDeviceCount failed: no usable HIP device"); }
     *count = n;
     return ZK_OK;
-}
+} ZK_GUARD
+// RAII: run a block on `device` and hand the caller's current device back (destructors and frees run from wherever the caller is)
+namespace {
+struct DeviceScope {
+    int prev = -1; bool switched = false;
+    explicit DeviceScope(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) switched = hipSetDevice(device) == hipSuccess;
+    }
+    ~DeviceScope() { if (switched && prev >= 0) (void)hipSetDevice(prev); }
+};
+}  // namespace
 static int use_device(int device) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(ZK_ERR_NODEVICE, "no HIP device (this library has no CPU path)");
@@ -179,30 +204,34 @@ extern "C" int zk_pk_from_parts(const uint64_t *alpha_g1, const uint64_t *beta_g
                                 const uint64_t *delta_g1, const uint64_t *delta_g2,
                                 uint32_t a_domain, uint32_t nA, const uint32_t *a_idx, const uint64_t *a_val,
                                 uint32_t b_domain, uint32_t nB, const uint32_t *b_idx, const uint64_t *b_val,
-                                uint32_t nH, const uint64_t *H, uint32_t nL, const uint64_t *L, zk_pk **out) {
+                                uint32_t nH, const uint64_t *H, uint32_t nL, const uint64_t *L, zk_pk **out) try {
     if (!alpha_g1 || !beta_g1 || !beta_g2 || !delta_g1 || !delta_g2 || !out) return fail(ZK_ERR_ARG, "null argument");
     if ((nA && (!a_idx || !a_val)) || (nB && (!b_idx || !b_val)) || (nH && !H) || (nL && !L)) return fail(ZK_ERR_ARG, "null query array");
-    zk_pk *pk = new (std::nothrow) zk_pk();
-    if (!pk) return ZK_ERR_NOMEM;
+    // sizes a domain of at most 2^28 (the 2-adicity of r - 1, src/stubs.cpp:49-75) can produce; anything larger is a caller error
+    const uint64_t lim = (1ull << 28) + 1;
+    if (a_domain > lim || b_domain > lim || nA > a_domain || nB > b_domain || nH > lim || nL > lim) return fail(ZK_ERR_ARG, "query sizes exceed their domain (or the 2^28 limit of the evaluation domain)");
+    std::unique_ptr<zk_pk> pk(new zk_pk());
+    // all host memory is claimed BEFORE the first byte of the caller's arrays is read: a size the host cannot hold ends in
+    // ZK_ERR_NOMEM (ZK_GUARD), not in a half-copied key
+    pk->a_idx.resize(nA); pk->b_idx.resize(nB); pk->a_val.resize(nA); pk->b_val.resize(nB); pk->H.resize(nH); pk->L.resize(nL);
     memcpy(&pk->alpha_g1, alpha_g1, 64); memcpy(&pk->beta_g1, beta_g1, 64); memcpy(&pk->beta_g2, beta_g2, 128);
     memcpy(&pk->delta_g1, delta_g1, 64); memcpy(&pk->delta_g2, delta_g2, 128);
     pk->a_domain = a_domain; pk->b_domain = b_domain;
-    pk->a_idx.assign(a_idx, a_idx + nA); pk->b_idx.assign(b_idx, b_idx + nB);
-    pk->a_val.resize(nA); if (nA) memcpy(pk->a_val.data(), a_val, 64 * (size_t)nA);
-    pk->b_val.resize(nB); if (nB) memcpy(pk->b_val.data(), b_val, 128 * (size_t)nB);
-    pk->H.resize(nH); if (nH) memcpy(pk->H.data(), H, 64 * (size_t)nH);
-    pk->L.resize(nL); if (nL) memcpy(pk->L.data(), L, 64 * (size_t)nL);
-    for (uint32_t k = 0; k < nA; k++) if (a_idx[k] >= a_domain || (k && a_idx[k] <= a_idx[k - 1])) { delete pk; return fail(ZK_ERR_ARG, "A_query indices must be ascending and inside the domain"); }
-    for (uint32_t k = 0; k < nB; k++) if (b_idx[k] >= b_domain || (k && b_idx[k] <= b_idx[k - 1])) { delete pk; return fail(ZK_ERR_ARG, "B_query indices must be ascending and inside the domain"); }
-    *out = pk;
+    if (nA) { memcpy(pk->a_idx.data(), a_idx, 4 * (size_t)nA); memcpy(pk->a_val.data(), a_val, 64 * (size_t)nA); }
+    if (nB) { memcpy(pk->b_idx.data(), b_idx, 4 * (size_t)nB); memcpy(pk->b_val.data(), b_val, 128 * (size_t)nB); }
+    if (nH) memcpy(pk->H.data(), H, 64 * (size_t)nH);
+    if (nL) memcpy(pk->L.data(), L, 64 * (size_t)nL);
+    for (uint32_t k = 0; k < nA; k++) if (a_idx[k] >= a_domain || (k && a_idx[k] <= a_idx[k - 1])) return fail(ZK_ERR_ARG, "A_query indices must be ascending and inside the domain");
+    for (uint32_t k = 0; k < nB; k++) if (b_idx[k] >= b_domain || (k && b_idx[k] <= b_idx[k - 1])) return fail(ZK_ERR_ARG, "B_query indices must be ascending and inside the domain");
+    *out = pk.release();
     return ZK_OK;
-}
-extern "C" int zk_pk_sizes(const zk_pk *pk, uint32_t s[6]) {
+} ZK_GUARD
+extern "C" int zk_pk_sizes(const zk_pk *pk, uint32_t s[6]) try {
     if (!pk || !s) return ZK_ERR_ARG;
     s[0] = pk->a_domain; s[1] = (uint32_t)pk->a_idx.size(); s[2] = pk->b_domain; s[3] = (uint32_t)pk->b_idx.size();
     s[4] = (uint32_t)pk->H.size(); s[5] = (uint32_t)pk->L.size();
     return ZK_OK;
-}
+} ZK_GUARD
 extern "C" const void *zk_pk_part(const zk_pk *pk, int which) {
     if (!pk) return nullptr;
     switch (which) {
@@ -213,7 +242,7 @@ extern "C" const void *zk_pk_part(const zk_pk *pk, int which) {
     }
 }
 namespace { void tables_drop_key(uint64_t pk_id); }
-extern "C" void zk_pk_free(zk_pk *pk) { if (pk) tables_drop_key(pk->id); delete pk; }
+extern "C" void zk_pk_free(zk_pk *pk) try { if (pk) tables_drop_key(pk->id); delete pk; } ZK_GUARD_VOID
 
 // ---- .raw stream under BINARY_OUTPUT + MONTGOMERY_OUTPUT + NO_PT_COMPRESSION (CMakeLists.txt:115-131,186-188):
 // point = ASCII '0'/'1' infinity flag + raw Montgomery limbs (G1: X Y; G2: X.c0 X.c1 Y.c0 Y.c1); infinity carries affine
@@ -228,40 +257,66 @@ namespace {
 bool codec_known(int codec) { return codec == ZK_CODEC_ALT_BN128 || codec == ZK_CODEC_MCL_BN128; }
 struct RawReader {
     FILE *f; int codec; bool bad = false;
+    uint64_t left = ~0ull;                  // bytes the stream can still hold (regular files: fstat size - position; pipes: unknown)
+    static constexpr uint64_t CHUNK = 1u << 16;   // elements a vector grows by while it is being read: nothing is allocated for
+                                                  // a count the stream has not yet proven it holds
+    RawReader(FILE *f_, int codec_) : f(f_), codec(codec_) {
+        struct stat st;
+        if (f && fstat(fileno(f), &st) == 0 && S_ISREG(st.st_mode)) { const off_t at = ftello(f); left = at >= 0 && st.st_size >= at ? (uint64_t)(st.st_size - at) : 0; }
+    }
+    int get() { const int c = fgetc(f); if (c != EOF && left != ~0ull && left) left--; return c; }
     template <class P> void point(P &p) {
-        int c = fgetc(f);
+        int c = get();
         if (c != '0' && c != '1') { bad = true; return; }
         if (fread(&p, sizeof(P), 1, f) != 1) { bad = true; return; }
+        if (left != ~0ull) left = left >= sizeof(P) ? left - sizeof(P) : 0;
         if (c == '1') memset(&p, 0, sizeof(P));
     }
     uint64_t size() {
         uint64_t v = 0; int c, nd = 0;
-        while ((c = fgetc(f)) >= '0' && c <= '9') { v = v * 10 + (uint64_t)(c - '0'); if (++nd > 12) { bad = true; return 0; } }
+        while ((c = get()) >= '0' && c <= '9') { v = v * 10 + (uint64_t)(c - '0'); if (++nd > 12) { bad = true; return 0; } }
         if (c != '\n' || nd == 0) bad = true;
         return v;
     }
+    // a declared element count is believed only as far as the rest of the stream can hold it (min_bytes per element)
+    bool fits(uint64_t n, uint64_t min_bytes) {
+        if (n > (1ull << 28) + 1) return false;
+        return left == ~0ull || n <= left / min_bytes;
+    }
     template <class P> void points(std::vector<P> &v, uint64_t n) {
         if (bad) return;
-        if (n > (1ull << 28) + 1) { bad = true; return; }
-        v.resize(n);
-        for (uint64_t i = 0; i < n && !bad; i++) point(v[i]);
+        if (!fits(n, 1 + sizeof(P))) { bad = true; return; }
+        v.clear();
+        for (uint64_t i = 0; i < n && !bad;) {
+            const uint64_t upto = n - i < CHUNK ? n : i + CHUNK;
+            v.resize(upto);
+            for (; i < upto && !bad; i++) point(v[i]);
+        }
     }
     // sparse_vector header: domain, indices; returns the value count
     uint64_t sparse_head(uint32_t &domain, std::vector<uint32_t> &idx) {
         if (bad) return 0;
-        domain = (uint32_t)size();
+        const uint64_t dom = size();
+        if (dom > (1ull << 28) + 1) { bad = true; return 0; }
+        domain = (uint32_t)dom;
         uint64_t n = size();
-        if (bad || n > (1ull << 28) + 1) { bad = true; return 0; }
-        idx.resize(n);
-        for (uint64_t i = 0; i < n && !bad; i++) {
-            idx[i] = (uint32_t)size();
-            if (idx[i] >= domain || (i && idx[i] <= idx[i - 1])) bad = true;
+        if (bad || n > dom || !fits(n, 2)) { bad = true; return 0; }       // an index is at least one digit and a newline
+        idx.clear();
+        for (uint64_t i = 0; i < n && !bad;) {
+            const uint64_t upto = n - i < CHUNK ? n : i + CHUNK;
+            idx.resize(upto);
+            for (; i < upto && !bad; i++) {
+                const uint64_t x = size();
+                idx[i] = (uint32_t)x;
+                if (x >= domain || (i && idx[i] <= idx[i - 1])) bad = true;
+            }
         }
         uint64_t nv = size();
         if (nv != n) bad = true;
         return bad ? 0 : nv;
     }
 };
+struct FileCloser { FILE *f; ~FileCloser() { if (f) fclose(f); } };
 struct RawWriter {
     FILE *f; int codec;
     G1::Affine i1; G2::Affine i2;
@@ -277,26 +332,25 @@ struct RawWriter {
 };
 }  // namespace
 
-extern "C" int zk_pk_load_raw(const char *path, int codec, zk_pk **out) {
+extern "C" int zk_pk_load_raw(const char *path, int codec, zk_pk **out) try {
     if (!path || !out) return fail(ZK_ERR_ARG, "null argument");
     if (!codec_known(codec)) return fail(ZK_ERR_ARG, "unsupported codec (ZK_CODEC_ALT_BN128 or ZK_CODEC_MCL_BN128)");
-    FILE *f = fopen(path, "rb");
+    FileCloser fc{fopen(path, "rb")};
+    FILE *f = fc.f;
     if (!f) return fail(ZK_ERR_IO, "cannot open proving key file");       // reference: assert(fh.is_open()), utils.hpp:180
-    zk_pk *pk = new (std::nothrow) zk_pk();
-    if (!pk) { fclose(f); return ZK_ERR_NOMEM; }
-    RawReader r{f, codec};
+    std::unique_ptr<zk_pk> pk(new zk_pk());                                 // (an exception on the way leaves nothing behind: ZK_GUARD)
+    RawReader r(f, codec);
     r.point(pk->alpha_g1); r.point(pk->beta_g1); r.point(pk->beta_g2); r.point(pk->delta_g1); r.point(pk->delta_g2);
     r.points(pk->a_val, r.sparse_head(pk->a_domain, pk->a_idx));
     r.points(pk->b_val, r.sparse_head(pk->b_domain, pk->b_idx));
     if (!r.bad) r.points(pk->H, r.size());
     if (!r.bad) r.points(pk->L, r.size());
-    fclose(f);
-    if (r.bad) { delete pk; return fail(ZK_ERR_FORMAT, "malformed .raw proving key stream"); }
-    *out = pk;
+    if (r.bad) return fail(ZK_ERR_FORMAT, "malformed .raw proving key stream (bad token, or a count the file cannot hold)");
+    *out = pk.release();
     return ZK_OK;
-}
+} ZK_GUARD
 
-extern "C" int zk_pk_save_raw(const zk_pk *pk, const char *path, int codec) {
+extern "C" int zk_pk_save_raw(const zk_pk *pk, const char *path, int codec) try {
     if (!pk || !path) return fail(ZK_ERR_ARG, "null argument");
     if (!codec_known(codec)) return fail(ZK_ERR_ARG, "unsupported codec (ZK_CODEC_ALT_BN128 or ZK_CODEC_MCL_BN128)");
     FILE *f = fopen(path, "wb");
@@ -309,7 +363,7 @@ extern "C" int zk_pk_save_raw(const zk_pk *pk, const char *path, int codec) {
     bool bad = ferror(f) != 0;
     if (fclose(f) != 0) bad = true;
     return bad ? fail(ZK_ERR_IO, "write error") : ZK_OK;
-}
+} ZK_GUARD
 
 // ---- the reference's offline key converters over the FULL (zero-knowledge) proving key stream, tcc:53-90:
 // alpha_g1 beta_g1 beta_g2 delta_g1 delta_g2, A_query (vector<G1>, V + 1 entries, zeros included), B_query
@@ -321,17 +375,20 @@ struct FullKey {
     uint32_t b_domain = 0; std::vector<uint32_t> b_idx; std::vector<G2::Affine> Bg;
 };
 int full_load(const char *path, int codec, FullKey &k) {
-    FILE *f = fopen(path, "rb");
+    FileCloser fc{fopen(path, "rb")};
+    FILE *f = fc.f;
     if (!f) return fail(ZK_ERR_IO, "cannot open proving key file");
-    RawReader r{f, codec};
+    RawReader r(f, codec);
     r.point(k.alpha_g1); r.point(k.beta_g1); r.point(k.beta_g2); r.point(k.delta_g1); r.point(k.delta_g2);
     if (!r.bad) r.points(k.A, r.size());
     const uint64_t nb = r.sparse_head(k.b_domain, k.b_idx);
-    k.Bg.resize(nb); k.Bh.resize(nb);
-    for (uint64_t i = 0; i < nb && !r.bad; i++) { r.point(k.Bg[i]); r.point(k.Bh[i]); }
+    if (!r.bad && !r.fits(nb, 2 + sizeof(G2::Affine) + sizeof(G1::Affine))) r.bad = true;
+    for (uint64_t i = 0; i < nb && !r.bad; i++) {
+        if (i % RawReader::CHUNK == 0) { const uint64_t upto = nb - i < RawReader::CHUNK ? nb : i + RawReader::CHUNK; k.Bg.resize(upto); k.Bh.resize(upto); }
+        r.point(k.Bg[i]); r.point(k.Bh[i]);
+    }
     if (!r.bad) r.points(k.H, r.size());
     if (!r.bad) r.points(k.L, r.size());
-    fclose(f);
     return r.bad ? fail(ZK_ERR_FORMAT, "malformed proving key stream") : ZK_OK;
 }
 int full_save(const char *path, int codec, const FullKey &k) {
@@ -374,7 +431,7 @@ bool through_decimal(G2::Affine &p) { return G2::is_inf(p) || (through_decimal(p
 }  // namespace
 
 // pk_alt2mcl (src/export.cpp:352-397)
-extern "C" int zk_pk_alt2mcl(const char *alt_pk_file, const char *mcl_pk_file) {
+extern "C" int zk_pk_alt2mcl(const char *alt_pk_file, const char *mcl_pk_file) try {
     if (!alt_pk_file || !mcl_pk_file) return fail(ZK_ERR_ARG, "null argument");
     FullKey k;
     ZK_TRY(full_load(alt_pk_file, ZK_CODEC_ALT_BN128, k));
@@ -386,10 +443,10 @@ extern "C" int zk_pk_alt2mcl(const char *alt_pk_file, const char *mcl_pk_file) {
     for (auto &p : k.L) ok = ok && through_decimal(p);
     if (!ok) return fail(ZK_ERR_FORMAT, "coordinate did not survive the decimal round trip");
     return full_save(mcl_pk_file, ZK_CODEC_MCL_BN128, k);
-}
+} ZK_GUARD
 
 // pk_mcl2nozk (src/export.cpp:399-408) = loadFromFile<full key> + the nozk conversion of hpp:209-233
-extern "C" int zk_pk_mcl2nozk(const char *mcl_pk_file, const char *nozk_pk_file) {
+extern "C" int zk_pk_mcl2nozk(const char *mcl_pk_file, const char *nozk_pk_file) try {
     if (!mcl_pk_file || !nozk_pk_file) return fail(ZK_ERR_ARG, "null argument");
     FullKey k;
     ZK_TRY(full_load(mcl_pk_file, ZK_CODEC_MCL_BN128, k));
@@ -400,7 +457,7 @@ extern "C" int zk_pk_mcl2nozk(const char *mcl_pk_file, const char *nozk_pk_file)
     pk.b_domain = k.b_domain; pk.b_idx = k.b_idx; pk.b_val = k.Bg;
     pk.H = k.H; pk.L = k.L;
     return zk_pk_save_raw(&pk, nozk_pk_file, ZK_CODEC_MCL_BN128);
-}
+} ZK_GUARD
 
 // ================================================================ context
 namespace {
@@ -506,7 +563,16 @@ struct DeviceTables {
     uint32_t cW = 0;                                   // window bits of the shared witness sort and of the tables it drives
     bool key_alive = true;                             // false once zk_pk_free has run: the last context to go takes the tables along
     int refs = 0;
+    // device memory of the set; leaves the caller's current device as it found it (zk_pk_free runs this from wherever the
+    // caller is -- Python's garbage collector inside a torch process -- and an eviction runs it in the middle of ctx_build)
+    void free_device() {
+        DeviceScope on(device);
+        void *dev[] = {tA, tH, tL, tB, dA_idx, dB_idx, posA, posB};
+        for (void *p : dev) if (p) hipFree(p);
+        tA = tH = tL = nullptr; tB = nullptr; dA_idx = dB_idx = posA = posB = nullptr;
+    }
 };
+struct DeviceTablesDeleter { void operator()(DeviceTables *t) const { if (t) { t->free_device(); delete t; } } };
 std::mutex g_tables_mu;
 std::vector<DeviceTables *> g_tables;
 
@@ -539,16 +605,16 @@ void tables_drop_key(uint64_t pk_id) {                  // zk_pk_free: every idl
         else { if (t->pk_id == pk_id) t->key_alive = false; i++; }
     }
 }
-// make room: drop the idle table sets of OTHER keys (least recently created first); true if something was freed
-bool tables_evict_idle_locked(uint64_t keep_pk) {
+// make room ON ONE DEVICE: drop an idle table set that lives there (least recently created first) -- of another key, or of this
+// key in another shape (shard, window, batch: a set the context being built cannot use); true if something was freed.
+// Sets on other devices are never touched: freeing them gives the device that is short of memory nothing.
+bool tables_evict_idle_locked(int device) {
     for (size_t i = 0; i < g_tables.size(); i++)
-        if (g_tables[i]->refs <= 0 && g_tables[i]->pk_id != keep_pk) { tables_free_locked(g_tables[i]); return true; }
+        if (g_tables[i]->refs <= 0 && g_tables[i]->device == device) { tables_free_locked(g_tables[i]); return true; }
     return false;
 }
 void tables_free_locked(DeviceTables *t) {
-    hipSetDevice(t->device);
-    void *dev[] = {t->tA, t->tH, t->tL, t->tB, t->dA_idx, t->dB_idx, t->posA, t->posB};
-    for (void *p : dev) if (p) hipFree(p);
+    t->free_device();
     for (size_t i = 0; i < g_tables.size(); i++) if (g_tables[i] == t) { g_tables.erase(g_tables.begin() + i); break; }
     delete t;
 }
@@ -615,6 +681,10 @@ struct zk_ctx {
     hipEvent_t ev_up = nullptr, ev_sort_h = nullptr;
     bool h_stream_made = false;
     bool latency_call = false;                 // the proof being queued came through a synchronous entry point (zk_prove ...)
+    // C = Ht + Lt is the only use of the H- and L-query results (tcc:540): when both multi-exponentiations have the same bucket set
+    // (same window bits) the L-query's chunk pieces are folded into the H-query's bucket reduction -- one tail (finalize, heavy, group
+    // reduce, tree sums) per proof less; zk_partials then carries the sum in Ht and the point at infinity in Lt.  ZK_NO_MERGE_HL=1: off.
+    bool merge_hl = false;
     // tuning aids, read from the environment ONCE at context creation (never on the proving path)
     bool env_no_direct_h2d = false;            // ZK_NO_DIRECT_H2D: synchronous proofs stage the witness through pinned memory too
     int env_h_stream = -1;                     // ZK_H_STREAM=0 / 1 forces the H pipeline onto s_main / a borrowed tail stream (-1: by size)
@@ -623,7 +693,7 @@ struct zk_ctx {
     hipEvent_t ev_start = nullptr, ev_w = nullptr, ev_h = nullptr, ev_a0 = nullptr, ev_a1 = nullptr, ev_b0 = nullptr, ev_b1 = nullptr,
                ev_l0 = nullptr, ev_l1 = nullptr, ev_h1 = nullptr, ev_h0 = nullptr;
     ~zk_ctx() {
-        hipSetDevice(device);
+        DeviceScope on(device);
         void *dev[] = {d_w, d_a, d_t, d_partials};           // d_b, d_c live inside d_a's allocation
         for (void *p : dev) if (p) hipFree(p);
         if (h_w) hipHostFree(h_w);
@@ -669,8 +739,8 @@ static int ctx_build(zk_ctx *c, const zk_pk *pk, const zk_csr *A, const zk_csr *
         for (DeviceTables *e : g_tables)
             if (e->pk_id == pk->id && e->device == c->device && e->rank == r && e->count == G && e->cbits == c->cfg.multi_exp_c && e->max_batch == c->max_batch) { t = e; break; }
         if (!t) {
-            t = new (std::nothrow) DeviceTables();
-            if (!t) return ZK_ERR_NOMEM;
+            std::unique_ptr<DeviceTables, DeviceTablesDeleter> fresh(new DeviceTables());      // (an error or exception below frees what was uploaded)
+            t = fresh.get();
             t->pk_id = pk->id; t->device = c->device; t->rank = r; t->count = G; t->cbits = c->cfg.multi_exp_c; t->max_batch = c->max_batch;
             // The A-, B- and L-query all read the witness: ONE bucket sort of the witness digits drives every query that is
             // dense in the window it covers.  Unsharded the window is the whole witness; a shard's window is the span of the
@@ -692,7 +762,7 @@ static int ctx_build(zk_ctx *c, const zk_pk *pk, const zk_csr *A, const zk_csr *
             {   // make room for this key's tables (5 GB at 2^20, 20 GB at 2^22): idle table sets of other keys go first
                 const uint64_t need = 16ull * (64ull * ((uint64_t)c->rA.n() + c->rH.n() + c->rL.n()) + 128ull * c->rB.n());
                 size_t mem_free = 0, mem_total = 0;
-                while (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess && need + (8ull << 30) > mem_free && tables_evict_idle_locked(pk->id)) {}
+                while (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess && need + (8ull << 30) > mem_free && tables_evict_idle_locked(c->device)) {}
             }
             auto window = [&](uint32_t n) { return t->cbits ? t->cbits : MsmShape::pick_c(n ? n : 1, t->max_batch); };
             t->cW = window(t->win_n);
@@ -718,13 +788,9 @@ static int ctx_build(zk_ctx *c, const zk_pk *pk, const zk_csr *A, const zk_csr *
             if (rc == ZK_OK) rc = build_table<G1>(&t->tH, pk->H.data() + c->rH.lo, c->rH.n(), t->cH);
             if (rc == ZK_OK) rc = build_table<G1>(&t->tL, pk->L.data() + c->rL.lo, c->rL.n(), t->cL);
             if (rc == ZK_OK) rc = build_table<G2>(&t->tB, pk->b_val.data() + c->rB.lo, c->rB.n(), t->cB);
-            if (rc != ZK_OK) {
-                void *dev[] = {t->tA, t->tH, t->tL, t->tB, t->dA_idx, t->dB_idx, t->posA, t->posB};
-                for (void *p : dev) if (p) hipFree(p);
-                delete t;
-                return rc;
-            }
+            if (rc != ZK_OK) return rc;
             g_tables.push_back(t);
+            fresh.release();
         }
         t->refs++;
         c->tables = t;
@@ -744,9 +810,12 @@ static int ctx_build(zk_ctx *c, const zk_pk *pk, const zk_csr *A, const zk_csr *
     ZK_HIP(hipMalloc(&c->d_a, 3 * 32 * (size_t)m * KB)); c->d_b = c->d_a + (size_t)m * KB; c->d_c = c->d_a + 2 * (size_t)m * KB;
     ZK_HIP(hipMalloc(&c->d_t, 3 * 32 * (size_t)m * KB));
     ZK_HIP(hipMalloc(&c->d_partials, sizeof(zk_partials) * KB));
+    ZK_HIP(hipMemset(c->d_partials, 0, sizeof(zk_partials) * KB));                  // (a merged H + L tail never writes Lt: it stays the point at infinity)
+    c->merge_hl = c->rH.n() && c->rL.n() && c->mH.sh.nb == c->mL.sh.nb && !getenv("ZK_NO_MERGE_HL");
     if (G > 1) {      // sharded provers exchange the device copy of their partial sums (zk_prove_collect_device)
         c->mA.dev_result = (G1::XYZZ *)(c->d_partials + offsetof(zk_partials, At)); c->mB.dev_result = (G2::XYZZ *)(c->d_partials + offsetof(zk_partials, Bt));
-        c->mH.dev_result = (G1::XYZZ *)(c->d_partials + offsetof(zk_partials, Ht)); c->mL.dev_result = (G1::XYZZ *)(c->d_partials + offsetof(zk_partials, Lt));
+        c->mH.dev_result = (G1::XYZZ *)(c->d_partials + offsetof(zk_partials, Ht));
+        if (!c->merge_hl) c->mL.dev_result = (G1::XYZZ *)(c->d_partials + offsetof(zk_partials, Lt));
     }
     c->mA.dev_result_pitch = c->mB.dev_result_pitch = c->mH.dev_result_pitch = c->mL.dev_result_pitch = sizeof(zk_partials);
     ZK_HIP(hipHostMalloc(&c->h_w, 32 * (size_t)(V + 1) * KB, hipHostMallocDefault));
@@ -798,7 +867,7 @@ static int ctx_build(zk_ctx *c, const zk_pk *pk, const zk_csr *A, const zk_csr *
 }
 
 extern "C" int zk_ctx_create(const zk_pk *pk, const zk_csr *A, const zk_csr *B, const zk_csr *C,
-                             uint32_t nC, uint32_t nIn, uint32_t V, const zk_config *cfg, zk_ctx **out) {
+                             uint32_t nC, uint32_t nIn, uint32_t V, const zk_config *cfg, zk_ctx **out) try {
     if (!pk || !A || !B || !C || !out) return fail(ZK_ERR_ARG, "null argument");
     if (A->n_rows != nC || B->n_rows != nC || C->n_rows != nC) return fail(ZK_ERR_ARG, "CSR row counts must equal nC");
     if (nIn > V) return fail(ZK_ERR_ARG, "nIn > V");
@@ -807,29 +876,28 @@ extern "C" int zk_ctx_create(const zk_pk *pk, const zk_csr *A, const zk_csr *B, 
     // the reference's DEBUG asserts, tcc:477-483, made unconditional
     if (pk->a_domain != V + 1 || pk->b_domain != V + 1 || pk->H.size() != (size_t)m - 1 || pk->L.size() != (size_t)(V - nIn))
         return fail(ZK_ERR_SHAPE, "proving key shape does not match (A/B domain = V+1, |H| = m-1, |L| = V-nIn)");
-    zk_ctx *c = new (std::nothrow) zk_ctx();
-    if (!c) return ZK_ERR_NOMEM;
+    std::unique_ptr<zk_ctx> holder(new zk_ctx());           // (whatever ends the construction early -- error code or exception -- releases it)
+    zk_ctx *c = holder.get();
     if (cfg) c->cfg = *cfg;
-    if (c->cfg.shard_count > 1 && c->cfg.shard_rank >= c->cfg.shard_count) { delete c; return fail(ZK_ERR_ARG, "shard_rank >= shard_count"); }
+    if (c->cfg.shard_count > 1 && c->cfg.shard_rank >= c->cfg.shard_count) return fail(ZK_ERR_ARG, "shard_rank >= shard_count");
     c->device = (int)c->cfg.device;
     c->max_batch = c->cfg.max_batch ? c->cfg.max_batch : 1;
-    if (c->max_batch > 4096) { delete c; return fail(ZK_ERR_ARG, "max_batch > 4096"); }
+    if (c->max_batch > 4096) return fail(ZK_ERR_ARG, "max_batch > 4096");
     c->nC = nC; c->nIn = nIn; c->V = V; c->m = m;
     while ((1u << c->logm) < m) c->logm++;
     c->alpha_g1 = pk->alpha_g1; c->beta_g2 = pk->beta_g2;
-    int rc = ctx_build(c, pk, A, B, C);
-    if (rc != ZK_OK) { delete c; return rc; }
-    *out = c;
+    ZK_TRY(ctx_build(c, pk, A, B, C));
+    *out = holder.release();
     return ZK_OK;
-}
+} ZK_GUARD
 // clients built against another layout of zk_config pass the size THEY know: missing trailing members read as 0 (their defaults)
 extern "C" int zk_ctx_create_sized(const zk_pk *pk, const zk_csr *A, const zk_csr *B, const zk_csr *C,
-                                   uint32_t nC, uint32_t nIn, uint32_t V, const zk_config *cfg, size_t cfg_size, zk_ctx **out) {
+                                   uint32_t nC, uint32_t nIn, uint32_t V, const zk_config *cfg, size_t cfg_size, zk_ctx **out) try {
     zk_config full{};
     if (cfg) memcpy(&full, cfg, cfg_size < sizeof(full) ? cfg_size : sizeof(full));
     return zk_ctx_create(pk, A, B, C, nC, nIn, V, cfg ? &full : nullptr, out);
-}
-extern "C" void zk_ctx_destroy(zk_ctx *ctx) { delete ctx; }
+} ZK_GUARD
+extern "C" void zk_ctx_destroy(zk_ctx *ctx) try { delete ctx; } ZK_GUARD_VOID
 
 // ---- "Compute the polynomial H" (tcc:460-475) on s_main; result in d_t (natural order), h[m-1] copied to h_tail
 // for the k = cur_batch proofs in flight: polynomials laid out [A: k x m][B: k x m][C: k x m] in d_a, h of proof p at d_t + p m
@@ -910,6 +978,7 @@ static void store_xyzz(uint64_t *dst, const G2::XYZZ &p) { memcpy(dst, &p, sizeo
 enum { PHASE_ALL = 0, PHASE_WITNESS = 1, PHASE_H = 2 };
 static int prove_enqueue(zk_ctx *c, const uint64_t *witness, int canonical, int resident, const fe *d_h, int phase);
 static void drain(zk_ctx *c) {
+    c->mL.tail_pending = c->mH.tail_pending = false;            // (a dropped proof's chunk pieces are not folded into the next one's reduction)
     hipStreamSynchronize(c->s_main); hipStreamSynchronize(c->s_acc); hipStreamSynchronize(c->s_a); hipStreamSynchronize(c->s_b); hipStreamSynchronize(c->s_l); hipStreamSynchronize(c->s_h);
 }
 static int prove_submit_impl(zk_ctx *c, const uint64_t *witness, int canonical, int resident = 0, uint32_t k = 1, const fe *d_h = nullptr, int phase = PHASE_ALL) {
@@ -999,13 +1068,19 @@ static int prove_enqueue(zk_ctx *c, const uint64_t *witness, int canonical, int 
     ZK_HIP(hipEventRecord(c->ev_a1, c->s_a));
     if (!t->share_L) { ZK_TRY(c->mL.enqueue_sort(c->d_w + (c->nIn + 1) + c->rL.lo, nullptr, c->rL.n(), 0, m, k, ws)); ZK_TRY(release()); }
     ZK_HIP(hipEventRecord(c->ev_l0, q));
-    ZK_TRY(c->mL.enqueue_reduce(t->share_L ? c->mW.view_for(t->offL) : c->mL.view(), q, c->s_l, tail_lanes));            // tcc:522-530
-    ZK_HIP(hipEventRecord(c->ev_l1, c->s_l));
+    if (c->merge_hl) {                                          // tcc:522-530; its chunk pieces wait for the H-query's bucket reduction (tcc:540: C = Ht + Lt)
+        ZK_TRY(c->mL.enqueue_accumulate(t->share_L ? c->mW.view_for(t->offL) : c->mL.view(), q));
+        ZK_HIP(hipEventRecord(c->ev_l1, q));
+    } else {
+        ZK_TRY(c->mL.enqueue_reduce(t->share_L ? c->mW.view_for(t->offL) : c->mL.view(), q, c->s_l, tail_lanes));
+        ZK_HIP(hipEventRecord(c->ev_l1, c->s_l));
+    }
     }
     if (phase == PHASE_WITNESS) return ZK_OK;                   // the H-query follows with zk_prove_submit_h
     if (!split_h) { ZK_TRY(h_pipeline()); ZK_TRY(release()); }
     else ZK_HIP(hipStreamWaitEvent(q, c->ev_sort_h, 0));
-    ZK_TRY(c->mH.enqueue_reduce(c->mH.view(), q, hs, tail_lanes));
+    ZK_TRY(c->mH.enqueue_accumulate(c->mH.view(), q));
+    ZK_TRY(c->mH.enqueue_tail(hs, tail_lanes, c->merge_hl ? &c->mL : nullptr));      // one bucket reduction for Ht + Lt
     ZK_HIP(hipEventRecord(c->ev_h1, hs));
     return ZK_OK;
 }
@@ -1055,24 +1130,24 @@ static int prove_partial_impl(zk_ctx *c, const uint64_t *witness, int canonical,
     return prove_collect_impl(c, out, tm);
 }
 // asynchronous form: enqueue a proof and return; collect later (lets two contexts keep the GPU full)
-extern "C" int zk_prove_submit(zk_ctx *ctx, const uint64_t *witness, int canonical) { return prove_submit_impl(ctx, witness, canonical); }
-extern "C" int zk_prove_submit_resident(zk_ctx *ctx, const void *d_witness, int canonical) { return prove_submit_impl(ctx, (const uint64_t *)d_witness, canonical, 1); }
+extern "C" int zk_prove_submit(zk_ctx *ctx, const uint64_t *witness, int canonical) try { return prove_submit_impl(ctx, witness, canonical); } ZK_GUARD
+extern "C" int zk_prove_submit_resident(zk_ctx *ctx, const void *d_witness, int canonical) try { return prove_submit_impl(ctx, (const uint64_t *)d_witness, canonical, 1); } ZK_GUARD
 // the witness lies in PINNED host memory ("witness already in pinned host memory"): the asynchronous H2D copy reads
 // the caller's buffer itself -- no copy into the context's staging buffer --, so the buffer stays untouched until the proof is collected
-extern "C" int zk_prove_submit_pinned(zk_ctx *ctx, const uint64_t *witness, int canonical) { return prove_submit_impl(ctx, witness, canonical, 3); }
-extern "C" int zk_prove_batch_submit_pinned(zk_ctx *ctx, const uint64_t *witnesses, uint32_t k, int canonical) { return prove_submit_impl(ctx, witnesses, canonical, 3, k); }
-extern "C" int zk_host_alloc(size_t bytes, void **out) {
+extern "C" int zk_prove_submit_pinned(zk_ctx *ctx, const uint64_t *witness, int canonical) try { return prove_submit_impl(ctx, witness, canonical, 3); } ZK_GUARD
+extern "C" int zk_prove_batch_submit_pinned(zk_ctx *ctx, const uint64_t *witnesses, uint32_t k, int canonical) try { return prove_submit_impl(ctx, witnesses, canonical, 3, k); } ZK_GUARD
+extern "C" int zk_host_alloc(size_t bytes, void **out) try {
     if (!out) return fail(ZK_ERR_ARG, "null argument");
     ZK_HIP(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
     return ZK_OK;
-}
-extern "C" int zk_host_free(void *p) { if (p) ZK_HIP(hipHostFree(p)); return ZK_OK; }
-extern "C" int zk_host_register(void *p, size_t bytes) {
+} ZK_GUARD
+extern "C" int zk_host_free(void *p) try { if (p) ZK_HIP(hipHostFree(p)); return ZK_OK; } ZK_GUARD
+extern "C" int zk_host_register(void *p, size_t bytes) try {
     if (!p || !bytes) return fail(ZK_ERR_ARG, "null argument");
     ZK_HIP(hipHostRegister(p, bytes, hipHostRegisterDefault));
     return ZK_OK;
-}
-extern "C" int zk_host_unregister(void *p) { if (p) ZK_HIP(hipHostUnregister(p)); return ZK_OK; }
+} ZK_GUARD
+extern "C" int zk_host_unregister(void *p) try { if (p) ZK_HIP(hipHostUnregister(p)); return ZK_OK; } ZK_GUARD
 // ---- double-buffered upload: the NEXT witness (k of them, contiguous) goes to the device on a copy stream while a
 // proof may still be in flight on this context; zk_prove_submit_staged then starts it with no upload on its critical path
 static int prove_stage_impl(zk_ctx *c, const uint64_t *witnesses, uint32_t k, int canonical, bool pinned) {
@@ -1099,10 +1174,10 @@ static int prove_stage_impl(zk_ctx *c, const uint64_t *witnesses, uint32_t k, in
     c->staged_k = k; c->staged_canonical = canonical;
     return ZK_OK;
 }
-extern "C" int zk_prove_stage(zk_ctx *c, const uint64_t *witnesses, uint32_t k, int canonical) { return prove_stage_impl(c, witnesses, k, canonical, false); }
+extern "C" int zk_prove_stage(zk_ctx *c, const uint64_t *witnesses, uint32_t k, int canonical) try { return prove_stage_impl(c, witnesses, k, canonical, false); } ZK_GUARD
 // the same from PINNED host memory: the copy stream reads the caller's buffer where it lies (untouched until that proof is collected)
-extern "C" int zk_prove_stage_pinned(zk_ctx *c, const uint64_t *witnesses, uint32_t k, int canonical) { return prove_stage_impl(c, witnesses, k, canonical, true); }
-extern "C" int zk_prove_submit_staged(zk_ctx *c) {
+extern "C" int zk_prove_stage_pinned(zk_ctx *c, const uint64_t *witnesses, uint32_t k, int canonical) try { return prove_stage_impl(c, witnesses, k, canonical, true); } ZK_GUARD
+extern "C" int zk_prove_submit_staged(zk_ctx *c) try {
     if (!c) return fail(ZK_ERR_ARG, "null argument");
     if (!c->staged_k) return fail(ZK_ERR_ARG, "no staged witness on this context (zk_prove_stage first)");
     if (c->in_flight) return fail(ZK_ERR_ARG, "a proof is already in flight on this context (collect it first)");
@@ -1112,9 +1187,9 @@ extern "C" int zk_prove_submit_staged(zk_ctx *c) {
     if (rc != ZK_OK) { std::swap(c->d_w, c->d_w2); return rc; }    // nothing is in flight (the failed submit was drained): the staged witness stays staged and can be submitted again
     c->staged_k = 0;
     return ZK_OK;
-}
+} ZK_GUARD
 // ---- SURVEY 8(e) option 2: the transform chains of the witness map on different ranks (ethsnarks_amd/sharded.py drives it)
-extern "C" int zk_chain_submit(zk_ctx *c, const uint64_t *witness, int canonical, int which) {
+extern "C" int zk_chain_submit(zk_ctx *c, const uint64_t *witness, int canonical, int which) try {
     if (!c || which < 0 || which > 2) return fail(ZK_ERR_ARG, "bad argument");
     ZK_TRY(use_device(c->device));
     if (c->in_flight && c->awaiting_h) {                        // the witness of the deferred proof is already on the device (same stream: ordered)
@@ -1126,53 +1201,53 @@ extern "C" int zk_chain_submit(zk_ctx *c, const uint64_t *witness, int canonical
     c->cur_batch = 1;
     ZK_TRY(upload_witness(c, witness, canonical));
     return enqueue_chain(c, which);
-}
+} ZK_GUARD
 extern "C" const void *zk_chain_device(const zk_ctx *c, int which) {
     if (!c || which < 0 || which > 2) return nullptr;
     return which == 2 ? c->d_t + 2 * (size_t)c->m : c->d_a + (size_t)which * c->m;       // A, B: coset evaluations; C: coefficients / Z(g)
 }
-extern "C" int zk_h_from_chains_submit(zk_ctx *c, const void *dA, const void *dB, const void *dC) {
+extern "C" int zk_h_from_chains_submit(zk_ctx *c, const void *dA, const void *dB, const void *dC) try {
     if (!c || !dA || !dB || !dC) return fail(ZK_ERR_ARG, "null argument");
     if (c->in_flight && !c->awaiting_h) return fail(ZK_ERR_ARG, "a proof is in flight on this context (collect it first)");
     ZK_TRY(use_device(c->device));
     return enqueue_h_from_chains(c, (const fe *)dA, (const fe *)dB, (const fe *)dC);
-}
+} ZK_GUARD
 extern "C" const void *zk_h_device(const zk_ctx *c) { return c ? c->d_t : nullptr; }
 // waits for the chain / h work queued so far; after zk_h_from_chains_submit it also checks the degree of h
-extern "C" int zk_chain_wait(zk_ctx *c, int check_degree) {
+extern "C" int zk_chain_wait(zk_ctx *c, int check_degree) try {
     if (!c) return fail(ZK_ERR_ARG, "null argument");
     ZK_TRY(use_device(c->device));
     ZK_HIP(hipStreamSynchronize(c->s_main));
     if (check_degree && !Fr::is_zero(c->h_tail[0])) return fail(ZK_ERR_DEGREE, "h[m-1] != 0: the witness does not satisfy the constraint system");
     return ZK_OK;
-}
-extern "C" int zk_prove_submit_with_h(zk_ctx *c, const uint64_t *witness, int canonical, const void *d_h) {
+} ZK_GUARD
+extern "C" int zk_prove_submit_with_h(zk_ctx *c, const uint64_t *witness, int canonical, const void *d_h) try {
     if (!d_h) return fail(ZK_ERR_ARG, "null argument");
     return prove_submit_impl(c, witness, canonical, 0, 1, (const fe *)d_h);
-}
+} ZK_GUARD
 // the same proof in two steps, so that the ranks of option 2 start their witness sorts and A-, B-, L-query accumulations BEFORE H
 // exists: zk_prove_submit_defer_h queues everything that needs only the witness; zk_chain_submit / zk_h_from_chains_submit may follow
 // on this context (witness = NULL: the deferred proof's witness is used); zk_prove_submit_h queues the H-query; collect as usual.
 // zk_prove_abort drops a proof that will not get its H part (another rank found the witness unsatisfying): drains, frees the context.
-extern "C" int zk_prove_submit_defer_h(zk_ctx *c, const uint64_t *witness, int canonical) { return prove_submit_impl(c, witness, canonical, 0, 1, nullptr, PHASE_WITNESS); }
-extern "C" int zk_prove_submit_h(zk_ctx *c, const void *d_h) { return prove_submit_impl(c, nullptr, 0, 0, 1, (const fe *)d_h, PHASE_H); }
-extern "C" int zk_prove_abort(zk_ctx *c) {
+extern "C" int zk_prove_submit_defer_h(zk_ctx *c, const uint64_t *witness, int canonical) try { return prove_submit_impl(c, witness, canonical, 0, 1, nullptr, PHASE_WITNESS); } ZK_GUARD
+extern "C" int zk_prove_submit_h(zk_ctx *c, const void *d_h) try { return prove_submit_impl(c, nullptr, 0, 0, 1, (const fe *)d_h, PHASE_H); } ZK_GUARD
+extern "C" int zk_prove_abort(zk_ctx *c) try {
     if (!c) return fail(ZK_ERR_ARG, "null argument");
     ZK_TRY(use_device(c->device));
     drain(c);
     c->in_flight = c->awaiting_h = false;
     return ZK_OK;
-}
+} ZK_GUARD
 
 // ---- several proofs of the circuit through ONE launch sequence: k witnesses, contiguous, k <= zk_config.max_batch
-extern "C" int zk_prove_batch_submit(zk_ctx *ctx, const uint64_t *witnesses, uint32_t k, int canonical) { return prove_submit_impl(ctx, witnesses, canonical, 0, k); }
-extern "C" int zk_prove_batch_submit_resident(zk_ctx *ctx, const void *d_witnesses, uint32_t k, int canonical) { return prove_submit_impl(ctx, (const uint64_t *)d_witnesses, canonical, 1, k); }
-extern "C" int zk_prove_batch_collect(zk_ctx *ctx, zk_partials *out, uint32_t k, zk_timings *t) {
+extern "C" int zk_prove_batch_submit(zk_ctx *ctx, const uint64_t *witnesses, uint32_t k, int canonical) try { return prove_submit_impl(ctx, witnesses, canonical, 0, k); } ZK_GUARD
+extern "C" int zk_prove_batch_submit_resident(zk_ctx *ctx, const void *d_witnesses, uint32_t k, int canonical) try { return prove_submit_impl(ctx, (const uint64_t *)d_witnesses, canonical, 1, k); } ZK_GUARD
+extern "C" int zk_prove_batch_collect(zk_ctx *ctx, zk_partials *out, uint32_t k, zk_timings *t) try {
     if (!ctx || !out) return fail(ZK_ERR_ARG, "null argument");
     if (ctx->in_flight && k != ctx->cur_batch) return fail(ZK_ERR_ARG, "collect: k differs from the submitted batch size");
     return prove_collect_impl(ctx, out, t);
-}
-extern "C" int zk_prove_batch(zk_ctx *ctx, const uint64_t *witnesses, uint32_t k, int canonical, zk_proof *out) {
+} ZK_GUARD
+extern "C" int zk_prove_batch(zk_ctx *ctx, const uint64_t *witnesses, uint32_t k, int canonical, zk_proof *out) try {
     if (!ctx || !out) return fail(ZK_ERR_ARG, "null argument");
     if (ctx->cfg.shard_count > 1) return fail(ZK_ERR_ARG, "sharded context: use zk_prove_batch_submit / _collect + zk_prove_combine per proof");
     ZK_TRY(prove_submit_impl(ctx, witnesses, canonical, 0, k));
@@ -1180,27 +1255,27 @@ extern "C" int zk_prove_batch(zk_ctx *ctx, const uint64_t *witnesses, uint32_t k
     ZK_TRY(prove_collect_impl(ctx, parts.data(), nullptr));
     for (uint32_t p = 0; p < k; p++) ZK_TRY(zk_prove_combine(ctx, &parts[p], 1, &out[p]));
     return ZK_OK;
-}
+} ZK_GUARD
 // what the context chose: {window bits, windows, buckets} of the A-, B-, H-, L-query MSMs, then whether the witness sort is shared
-extern "C" int zk_ctx_info(const zk_ctx *c, uint32_t info[16]) {
+extern "C" int zk_ctx_info(const zk_ctx *c, uint32_t info[16]) try {
     if (!c || !info) return fail(ZK_ERR_ARG, "null argument");
     const MsmShape *sh[4] = {&c->mA.sh, &c->mB.sh, &c->mH.sh, &c->mL.sh};
     for (int i = 0; i < 4; i++) { info[3 * i] = sh[i]->c; info[3 * i + 1] = sh[i]->W; info[3 * i + 2] = sh[i]->nb; }
     info[12] = c->tables->share_A; info[13] = c->tables->share_B; info[14] = c->tables->share_L; info[15] = c->m;
     return ZK_OK;
-}
-extern "C" int zk_prove_collect(zk_ctx *ctx, zk_partials *out, zk_timings *t) {
+} ZK_GUARD
+extern "C" int zk_prove_collect(zk_ctx *ctx, zk_partials *out, zk_timings *t) try {
     if (!ctx || !out) return fail(ZK_ERR_ARG, "null argument");
     if (ctx->in_flight && ctx->cur_batch != 1) return fail(ZK_ERR_ARG, "a batch is in flight: use zk_prove_batch_collect");
     return prove_collect_impl(ctx, out, t);
-}
+} ZK_GUARD
 // device-side exchange of sharded provers: the partial sums stay in a 640-byte device buffer of the context (zk_partials layout,
 // loose Montgomery values), ready for an RCCL all-gather; zk_prove_combine_device takes the gathered device buffer
 extern "C" const void *zk_ctx_partials_device(const zk_ctx *ctx) { return ctx ? ctx->d_partials : nullptr; }
-extern "C" int zk_prove_collect_device(zk_ctx *ctx, zk_timings *t) {
+extern "C" int zk_prove_collect_device(zk_ctx *ctx, zk_timings *t) try {
     if (ctx && ctx->cfg.shard_count <= 1) return fail(ZK_ERR_ARG, "zk_prove_collect_device: only sharded contexts keep a device copy of their partial sums");
     return prove_collect_impl(ctx, nullptr, t);
-}
+} ZK_GUARD
 
 template <class F> static void canon4(uint64_t dst[4], const fe &mont) { fe c = F::from_mont(mont); memcpy(dst, c.l, 32); }
 static void put_g1(const G1::XYZZ &p, uint64_t x[4], uint64_t y[4], uint32_t *inf) {
@@ -1215,7 +1290,7 @@ static void put_g2(const G2::XYZZ &p, uint64_t xc0[4], uint64_t xc1[4], uint64_t
 }
 
 // "Compute the proof" tail, tcc:533-546: A = alpha + At, B = beta + Bt, C = Ht + Lt; partials folded in rank order
-extern "C" int zk_prove_combine(const zk_ctx *c, const zk_partials *parts, uint32_t count, zk_proof *out) {
+extern "C" int zk_prove_combine(const zk_ctx *c, const zk_partials *parts, uint32_t count, zk_proof *out) try {
     if (!c || !parts || !count || !out) return fail(ZK_ERR_ARG, "null argument");
     G1::XYZZ At = G1::infinity(), Ht = G1::infinity(), Lt = G1::infinity(); G2::XYZZ Bt = G2::infinity();
     for (uint32_t i = 0; i < count; i++) {
@@ -1232,9 +1307,9 @@ extern "C" int zk_prove_combine(const zk_ctx *c, const zk_partials *parts, uint3
     put_g2(gB, out->b_x_c0, out->b_x_c1, out->b_y_c0, out->b_y_c1, &out->b_inf);
     put_g1(gC, out->c_x, out->c_y, &out->c_inf);
     return ZK_OK;
-}
+} ZK_GUARD
 
-extern "C" int zk_prove_combine_device(const zk_ctx *c, const void *d_parts, uint32_t count, zk_proof *out) {
+extern "C" int zk_prove_combine_device(const zk_ctx *c, const void *d_parts, uint32_t count, zk_proof *out) try {
     if (!c || !d_parts || !count || !out) return fail(ZK_ERR_ARG, "null argument");
     ZK_TRY(use_device(c->device));
     std::vector<zk_partials> parts(count);
@@ -1245,15 +1320,15 @@ extern "C" int zk_prove_combine_device(const zk_ctx *c, const void *d_parts, uin
         store_xyzz(p.At, G1::canon(a)); store_xyzz(p.Bt, G2::canon(b)); store_xyzz(p.Ht, G1::canon(h)); store_xyzz(p.Lt, G1::canon(l));
     }
     return zk_prove_combine(c, parts.data(), count, out);
-}
+} ZK_GUARD
 
-extern "C" int zk_prove_partial(zk_ctx *ctx, const uint64_t *witness, int canonical, zk_partials *out) {
+extern "C" int zk_prove_partial(zk_ctx *ctx, const uint64_t *witness, int canonical, zk_partials *out) try {
     return prove_partial_impl(ctx, witness, canonical, out, nullptr);
-}
-extern "C" int zk_prove_partial_timed(zk_ctx *ctx, const uint64_t *witness, int canonical, zk_partials *out, zk_timings *t) {
+} ZK_GUARD
+extern "C" int zk_prove_partial_timed(zk_ctx *ctx, const uint64_t *witness, int canonical, zk_partials *out, zk_timings *t) try {
     return prove_partial_impl(ctx, witness, canonical, out, t);
-}
-extern "C" int zk_prove_timed(zk_ctx *ctx, const uint64_t *witness, int canonical, zk_proof *out, zk_timings *t) {
+} ZK_GUARD
+extern "C" int zk_prove_timed(zk_ctx *ctx, const uint64_t *witness, int canonical, zk_proof *out, zk_timings *t) try {
     if (!ctx || !out) return fail(ZK_ERR_ARG, "null argument");
     if (ctx->cfg.shard_count > 1) return fail(ZK_ERR_ARG, "sharded context: use zk_prove_partial + zk_prove_combine");
     zk_partials p;
@@ -1262,16 +1337,16 @@ extern "C" int zk_prove_timed(zk_ctx *ctx, const uint64_t *witness, int canonica
     ZK_TRY(zk_prove_combine(ctx, &p, 1, out));
     if (t) t->host_finish += (float)(now_ms() - t0);
     return ZK_OK;
-}
-extern "C" int zk_prove(zk_ctx *ctx, const uint64_t *witness, int canonical, zk_proof *out) {
+} ZK_GUARD
+extern "C" int zk_prove(zk_ctx *ctx, const uint64_t *witness, int canonical, zk_proof *out) try {
     return zk_prove_timed(ctx, witness, canonical, out, nullptr);
-}
+} ZK_GUARD
 
 
 // ================================================================ key generation
 // r1cs_gg_ppzksnark_zok_generator (tcc:277-449) with r1cs_to_qap_instance_map_with_evaluation
 //  and the zk -> nozk conversion of hpp:209-233.
-extern "C" void zk_vk_free(zk_vk *vk) { delete vk; }
+extern "C" void zk_vk_free(zk_vk *vk) try { delete vk; } ZK_GUARD_VOID
 
 namespace {
 // standard alt_bn128 G2 generator, canonical 32-bit limbs: x.c0, x.c1, y.c0, y.c1
@@ -1309,7 +1384,7 @@ int batch_mul_host(const typename C::Affine &base, const std::vector<fe> &scalar
 }  // namespace
 
 extern "C" int zk_keygen(const zk_csr *A, const zk_csr *B, const zk_csr *C, uint32_t nC, uint32_t nIn, uint32_t V,
-                         const uint64_t toxic_canon[20], int device, zk_pk **pk_out, zk_vk **vk_out) {
+                         const uint64_t toxic_canon[20], int device, zk_pk **pk_out, zk_vk **vk_out) try {
     if (!A || !B || !C || !toxic_canon || !pk_out || !vk_out) return fail(ZK_ERR_ARG, "null argument");
     if (A->n_rows != nC || B->n_rows != nC || C->n_rows != nC || nIn > V) return fail(ZK_ERR_ARG, "inconsistent constraint system");
     if ((uint64_t)nC + nIn + 1 > (1ull << 28)) return fail(ZK_ERR_ARG, "domain exceeds 2^28");
@@ -1351,8 +1426,7 @@ extern "C" int zk_keygen(const zk_csr *A, const zk_csr *B, const zk_csr *C, uint
     const fe gi = Fr::inv(gamma), di = Fr::inv(delta);
     // G1 scalars: [alpha, beta, delta | gammaABC (nIn+1) | A (non-zero) | H (m-1) | L (V-nIn)]
     std::vector<fe> s1, s2;
-    zk_pk *pk = new (std::nothrow) zk_pk(); zk_vk *vk = new (std::nothrow) zk_vk();
-    if (!pk || !vk) { delete pk; delete vk; return ZK_ERR_NOMEM; }
+    std::unique_ptr<zk_pk> pk(new zk_pk()); std::unique_ptr<zk_vk> vk(new zk_vk());
     pk->a_domain = V + 1; pk->b_domain = V + 1;
     s1.push_back(alpha); s1.push_back(beta); s1.push_back(delta);
     s2.push_back(beta); s2.push_back(gamma); s2.push_back(delta);
@@ -1376,7 +1450,7 @@ extern "C" int zk_keygen(const zk_csr *A, const zk_csr *B, const zk_csr *C, uint
     std::vector<G1::Affine> o1; std::vector<G2::Affine> o2;
     int rc = batch_mul_host<G1>(g1, s1, o1);
     if (rc == ZK_OK) rc = batch_mul_host<G2>(g2, s2, o2);
-    if (rc != ZK_OK) { delete pk; delete vk; return rc; }
+    if (rc != ZK_OK) return rc;
     size_t k = 0;
     pk->alpha_g1 = o1[k++]; pk->beta_g1 = o1[k++]; pk->delta_g1 = o1[k++];
     vk->gamma_abc.assign(o1.begin() + k, o1.begin() + k + nIn + 1); k += nIn + 1;
@@ -1386,9 +1460,9 @@ extern "C" int zk_keygen(const zk_csr *A, const zk_csr *B, const zk_csr *C, uint
     pk->beta_g2 = o2[0]; pk->delta_g2 = o2[2];
     pk->b_val.assign(o2.begin() + 3, o2.end());
     vk->alpha_g1 = pk->alpha_g1; vk->beta_g2 = o2[0]; vk->gamma_g2 = o2[1]; vk->delta_g2 = o2[2];
-    *pk_out = pk; *vk_out = vk;
+    *pk_out = pk.release(); *vk_out = vk.release();
     return ZK_OK;
-}
+} ZK_GUARD
 
 // ================================================================ witness completion on the GPU
 // The reference fills pb.values on the host, gadget by gadget (generate_r1cs_witness).  For circuits whose constraints are in
@@ -1506,7 +1580,7 @@ struct zk_wplan {
     fe *d_coefs = nullptr;
     hipStream_t st = nullptr;
     ~zk_wplan() {
-        hipSetDevice(device);
+        DeviceScope on(device);
         if (d_tape) hipFree(d_tape);
         if (d_viol) hipFree(d_viol);
         if (d_coefs) hipFree(d_coefs);
@@ -1515,11 +1589,11 @@ struct zk_wplan {
 };
 
 extern "C" int zk_wplan_create(const zk_csr *A, const zk_csr *B, const zk_csr *C, uint32_t nC, uint32_t V,
-                               const uint8_t *known, int device, zk_wplan **out) {
+                               const uint8_t *known, int device, zk_wplan **out) try {
     return zk_wplan_create_hinted(A, B, C, nC, V, known, nullptr, 0, device, out);
-}
+} ZK_GUARD
 extern "C" int zk_wplan_create_hinted(const zk_csr *A, const zk_csr *B, const zk_csr *C, uint32_t nC, uint32_t V,
-                                      const uint8_t *known, const zk_whint *hints, uint32_t n_hints, int device, zk_wplan **out) {
+                                      const uint8_t *known, const zk_whint *hints, uint32_t n_hints, int device, zk_wplan **out) try {
     if (!A || !B || !C || !known || !out || (n_hints && !hints)) return fail(ZK_ERR_ARG, "null argument");
     if (A->n_rows != nC || B->n_rows != nC || C->n_rows != nC) return fail(ZK_ERR_ARG, "CSR row counts must equal nC");
     if (V >= (1u << 28)) return fail(ZK_ERR_ARG, "witness plan: more than 2^28 variables");
@@ -1636,21 +1710,20 @@ extern "C" int zk_wplan_create_hinted(const zk_csr *A, const zk_csr *B, const zk
     const uint32_t n_records = (uint32_t)(tape.size() / WP_WORDS);
     tape.insert(tape.end(), 3 * WP_WORDS, 0u);                       // the read-ahead past the last record finds empty records
     if (coefs.empty()) coefs.push_back(one);
-    zk_wplan *p = new (std::nothrow) zk_wplan();
-    if (!p) return ZK_ERR_NOMEM;
+    std::unique_ptr<zk_wplan> p(new zk_wplan());
     p->device = device; p->nC = nC; p->V = V; p->n_records = n_records;
     int rc = dev_upload(&p->d_tape, tape.data(), tape.size());
     if (rc == ZK_OK) rc = dev_upload(&p->d_coefs, coefs.data(), coefs.size());
     if (rc == ZK_OK && hipMalloc(&p->d_viol, 4) != hipSuccess) rc = ZK_ERR_NOMEM;
     if (rc == ZK_OK && hipStreamCreateWithFlags(&p->st, hipStreamNonBlocking) != hipSuccess) rc = ZK_ERR_HIP;
-    if (rc != ZK_OK) { delete p; return rc; }
-    *out = p;
+    if (rc != ZK_OK) return rc;
+    *out = p.release();
     return ZK_OK;
-}
-extern "C" void zk_wplan_free(zk_wplan *p) { delete p; }
+} ZK_GUARD
+extern "C" void zk_wplan_free(zk_wplan *p) try { delete p; } ZK_GUARD_VOID
 // d_w: k witnesses, (V + 1) x 32 bytes each, contiguous, device memory, Montgomery; the supplied variables (and ONE at index
 // 0) filled in.  Completes them in place; *violations = constraints (over all k) that introduce nothing and do not hold.
-extern "C" int zk_wplan_solve(zk_wplan *p, void *d_w, uint32_t k, uint32_t *violations) {
+extern "C" int zk_wplan_solve(zk_wplan *p, void *d_w, uint32_t k, uint32_t *violations) try {
     if (!p || !d_w || !k) return fail(ZK_ERR_ARG, "bad argument");
     ZK_TRY(use_device(p->device));
     ZK_HIP(hipMemsetAsync(p->d_viol, 0, 4, p->st));
@@ -1660,17 +1733,17 @@ extern "C" int zk_wplan_solve(zk_wplan *p, void *d_w, uint32_t k, uint32_t *viol
     ZK_HIP(hipStreamSynchronize(p->st));
     if (violations) *violations = v;
     return ZK_OK;
-}
+} ZK_GUARD
 // plain device-memory helpers for hosts that have no HIP binding of their own (tests, ctypes clients)
-extern "C" int zk_dev_alloc(size_t bytes, int device, void **out) {
+extern "C" int zk_dev_alloc(size_t bytes, int device, void **out) try {
     if (!out) return fail(ZK_ERR_ARG, "null argument");
     ZK_TRY(use_device(device));
     ZK_HIP(hipMalloc(out, bytes ? bytes : 1));
     return ZK_OK;
-}
-extern "C" int zk_dev_free(void *p) { return (!p || hipFree(p) == hipSuccess) ? ZK_OK : ZK_ERR_HIP; }
-extern "C" int zk_dev_upload(void *dst, const void *src, size_t bytes) { if (!dst || !src) return fail(ZK_ERR_ARG, "null argument"); ZK_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return ZK_OK; }
-extern "C" int zk_dev_download(void *dst, const void *src, size_t bytes) { if (!dst || !src) return fail(ZK_ERR_ARG, "null argument"); ZK_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return ZK_OK; }
+} ZK_GUARD
+extern "C" int zk_dev_free(void *p) try { return (!p || hipFree(p) == hipSuccess) ? ZK_OK : ZK_ERR_HIP; } ZK_GUARD
+extern "C" int zk_dev_upload(void *dst, const void *src, size_t bytes) try { if (!dst || !src) return fail(ZK_ERR_ARG, "null argument"); ZK_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return ZK_OK; } ZK_GUARD
+extern "C" int zk_dev_download(void *dst, const void *src, size_t bytes) try { if (!dst || !src) return fail(ZK_ERR_ARG, "null argument"); ZK_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return ZK_OK; } ZK_GUARD
 
 // ================================================================ JSON (src/export.cpp:20-121)
 namespace {
@@ -1687,7 +1760,7 @@ void q(std::string &s, const uint64_t v[4]) { s += "\"0x"; hex_canon(s, v); s +=
 }  // namespace
 
 extern "C" int zk_proof_to_json(const zk_proof *p, const uint64_t *inputs, uint32_t nIn, int canonical,
-                                char *buf, size_t cap, size_t *len) {
+                                char *buf, size_t cap, size_t *len) try {
     if (!p || (nIn && !inputs) || !len) return fail(ZK_ERR_ARG, "null argument");
     std::string s;
     s.reserve(1024 + 70 * (size_t)nIn);
@@ -1708,11 +1781,11 @@ extern "C" int zk_proof_to_json(const zk_proof *p, const uint64_t *inputs, uint3
     if (!buf || cap < s.size() + 1) return fail(ZK_ERR_BUFFER, "JSON buffer too small");
     memcpy(buf, s.data(), s.size()); buf[s.size()] = 0;
     return ZK_OK;
-}
+} ZK_GUARD
 
 
 // vk2json, src/export.cpp:124-145
-extern "C" int zk_vk_to_json(const zk_vk *vk, char *buf, size_t cap, size_t *len) {
+extern "C" int zk_vk_to_json(const zk_vk *vk, char *buf, size_t cap, size_t *len) try {
     if (!vk || !len) return fail(ZK_ERR_ARG, "null argument");
     std::string s;
     auto g1 = [&](const G1::Affine &p) {
@@ -1736,10 +1809,10 @@ extern "C" int zk_vk_to_json(const zk_vk *vk, char *buf, size_t cap, size_t *len
     if (!buf || cap < s.size() + 1) return fail(ZK_ERR_BUFFER, "JSON buffer too small");
     memcpy(buf, s.data(), s.size()); buf[s.size()] = 0;
     return ZK_OK;
-}
+} ZK_GUARD
 
 // ================================================================ kernel-level entry points (tests / micro-benchmarks)
-extern "C" int zk_ntt(uint64_t *data, uint32_t logm, int inverse, int coset, int device) {
+extern "C" int zk_ntt(uint64_t *data, uint32_t logm, int inverse, int coset, int device) try {
     if (!data || logm > 28) return fail(ZK_ERR_ARG, "bad argument");
     ZK_TRY(use_device(device));
     NttTables tab; fe *d_in = nullptr, *d_out = nullptr;
@@ -1759,9 +1832,9 @@ extern "C" int zk_ntt(uint64_t *data, uint32_t logm, int inverse, int coset, int
     if (d_out) hipFree(d_out);
     ntt_tables_free(tab);
     return rc;
-}
+} ZK_GUARD
 
-extern "C" int zk_witness_map(zk_ctx *c, const uint64_t *witness, int canonical, uint64_t *h_out) {
+extern "C" int zk_witness_map(zk_ctx *c, const uint64_t *witness, int canonical, uint64_t *h_out) try {
     if (!c || !witness || !h_out) return fail(ZK_ERR_ARG, "null argument");
     if (c->in_flight) return fail(ZK_ERR_ARG, "a proof is in flight on this context (collect it first): its witness and H buffers are in use");
     ZK_TRY(use_device(c->device));
@@ -1772,7 +1845,7 @@ extern "C" int zk_witness_map(zk_ctx *c, const uint64_t *witness, int canonical,
     ZK_HIP(hipMemcpy(h_out, c->d_t, 32 * (size_t)c->m, hipMemcpyDeviceToHost));
     memset(h_out + 4 * (size_t)c->m, 0, 32);
     return ZK_OK;
-}
+} ZK_GUARD
 
 template <class C>
 static int msm_host(const uint64_t *bases, const uint64_t *scalars, uint32_t n, uint32_t cbits, int device, uint64_t *out_affine) {
@@ -1795,15 +1868,15 @@ static int msm_host(const uint64_t *bases, const uint64_t *scalars, uint32_t n, 
     if (d_scalars) hipFree(d_scalars);
     return rc;
 }
-extern "C" int zk_msm_g1(const uint64_t *bases, const uint64_t *scalars, uint32_t n, uint32_t c, int device, uint64_t out[8]) {
+extern "C" int zk_msm_g1(const uint64_t *bases, const uint64_t *scalars, uint32_t n, uint32_t c, int device, uint64_t out[8]) try {
     return msm_host<G1>(bases, scalars, n, c, device, out);
-}
-extern "C" int zk_msm_g2(const uint64_t *bases, const uint64_t *scalars, uint32_t n, uint32_t c, int device, uint64_t out[16]) {
+} ZK_GUARD
+extern "C" int zk_msm_g2(const uint64_t *bases, const uint64_t *scalars, uint32_t n, uint32_t c, int device, uint64_t out[16]) try {
     return msm_host<G2>(bases, scalars, n, c, device, out);
-}
+} ZK_GUARD
 
 // host-only: Fr elements between the canonical and the Montgomery (libff::Fp_model) representation, in place
-extern "C" int zk_fr_convert(uint64_t *io, uint32_t n, int to_montgomery) {
+extern "C" int zk_fr_convert(uint64_t *io, uint32_t n, int to_montgomery) try {
     if (n && !io) return fail(ZK_ERR_ARG, "null argument");
     for (uint32_t i = 0; i < n; i++) {
         fe v; memcpy(v.l, io + 4 * (size_t)i, 32);
@@ -1811,9 +1884,9 @@ extern "C" int zk_fr_convert(uint64_t *io, uint32_t n, int to_montgomery) {
         memcpy(io + 4 * (size_t)i, v.l, 32);
     }
     return ZK_OK;
-}
+} ZK_GUARD
 
-extern "C" int zk_field_mul(const uint64_t *a, const uint64_t *b, uint64_t *out, uint32_t n, int field, int device) {
+extern "C" int zk_field_mul(const uint64_t *a, const uint64_t *b, uint64_t *out, uint32_t n, int field, int device) try {
     if (!a || !b || !out) return fail(ZK_ERR_ARG, "null argument");
     ZK_TRY(use_device(device));
     fe *da = nullptr, *db = nullptr, *dout = nullptr;
@@ -1827,4 +1900,4 @@ extern "C" int zk_field_mul(const uint64_t *a, const uint64_t *b, uint64_t *out,
     if (db) hipFree(db);
     if (dout) hipFree(dout);
     return rc;
-}
+} ZK_GUARD

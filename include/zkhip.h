@@ -48,6 +48,7 @@ extern "C" {
 #define ZK_ERR_DEGREE 7    /* H has wrong degree: witness does not satisfy the R1CS (asserts tcc:472-474) */
 #define ZK_ERR_NODEVICE 8
 #define ZK_ERR_BUFFER 9    /* output buffer too small */
+#define ZK_ERR_INTERNAL 10 /* an exception other than an allocation failure reached the C ABI's barrier (text in zk_last_error) */
 
 #define ZK_CODEC_ALT_BN128 0   /* upstream libff alt_bn128 stream layout */
 #define ZK_CODEC_MCL_BN128 1   /* the reference's default curve build (CMakeLists.txt:47-54); its element encoding lives in the
@@ -104,7 +105,9 @@ typedef struct {
 } zk_proof;
 
 /* per-shard partial results of the four multi-exponentiations, XYZZ coordinates, Montgomery:
- * At, Ht, Lt: 4 x 4 u64 each (G1); Bt: 4 x 8 u64 (G2)  => 3*128 + 256 = 640 bytes */
+ * At, Ht, Lt: 4 x 4 u64 each (G1); Bt: 4 x 8 u64 (G2)  => 3*128 + 256 = 640 bytes.
+ * The proof only ever uses Ht + Lt (C = Ht + Lt, tcc:540): when the H- and the L-query share their bucket set (the usual case)
+ * ONE bucket reduction serves both, Ht carries the sum and Lt the point at infinity (all zero); zk_prove_combine adds them either way. */
 typedef struct {
     uint64_t At[16], Bt[32], Ht[16], Lt[16];
 } zk_partials;
