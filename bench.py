@@ -51,7 +51,18 @@ WITNESS_NOTE = {
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 MAD_LANE_OPS_PER_CLK_CU = 43.4  # measured v_mad_u64_u32 rate, tools/microbench (profiles/r01_microbench.txt)
 MADS_PER_G2_MADD = 6 * 400 + 2 * 272 + 656   # = 3600: 6 Fq2 products (2 x (2 x 64 + 72)), 2 Fq2 squarings (2 x 136), one 2-term Fq2 dot product (2 x (4 x 64 + 72))
-PMC_PROFILE = os.path.join("profiles", "r03_pmc_traffic.json")
+PMC_PROFILE = os.path.join("profiles", "r04_pmc_traffic.json")
+KERNEL_SOURCES = ["msm.hpp", "msm_impl.hpp", "bn254.hpp", "fips_asm.hpp"]     # what k_msm_accumulate is compiled from (ethsnarks_amd/csrc)
+
+
+def kernel_sources_sha16():
+    """identity of the accumulation kernels' sources: the committed PMC passes name the sources they were taken with, and
+    roofline.traffic is only quoted while they are still the ones this library was built from (tools/pmc_summary.py writes the same digest)"""
+    import hashlib
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, "ethsnarks_amd", "csrc", name), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def main():
@@ -188,19 +199,15 @@ def main():
         if witness in ("host", "host-direct"):                      # the witness lies in pinned host memory
             pinned = P.PinnedBuffer(wmk.nbytes)
             pinned.array[:] = wmk.reshape(-1)
-        sharded = [ShardedProver(c, dist, torch.device("cuda", local_rank)) for c in ctxs] if (shard and not gloo) else None
-        gather_buf = torch.empty((world, 640), dtype=torch.uint8) if (shard and gloo) else None
+        # (under the one-GPU rehearsal, ZK_BENCH_REHEARSE=1, ShardedProver stages every exchanged buffer through the host: gloo moves host memory only)
+        sharded = [ShardedProver(c, dist, torch.device("cuda", local_rank)) for c in ctxs] if shard else None
         acc_b, pending, state = [], [], {"t": {}}
         use_stage = witness in ("host", "host-pageable-staged") and not shard
         staged = [False] * len(ctxs)
 
         def finish(slot):
             """collect slot's proof; sharded: one all-gather of the 640-byte partials (device buffers), folded in rank order"""
-            if shard and gloo:                                  # rehearsal on one GPU: gloo cannot see device memory
-                part, tm = ctxs[slot].collect()
-                dist.all_gather_into_tensor(gather_buf.view(-1), torch.from_numpy(part.view(np.uint8).copy()))
-                proof = ctxs[slot].prove_combine(gather_buf.numpy().reshape(-1).view(np.uint64))
-            elif shard:
+            if shard:
                 proof, tm = sharded[slot].finish()
             elif kb > 1:
                 parts, tm = ctxs[slot].collect_batch(kb)
@@ -316,7 +323,7 @@ def main():
                                              "matches_replica_proof": s2["json"] == js}
                 except Exception as e:                              # the headline line must survive a failure of an extra leg
                     extras["msm_sharded"] = {"error": repr(e)[:300]}
-                if world >= 3 and not gloo:                         # SURVEY 8(e) option 2: A / B / C transform chains on three ranks, one proof at a time
+                if world >= 3:                                      # SURVEY 8(e) option 2: A / B / C transform chains on three ranks, one proof at a time
                     try:
                         ctx2 = P.ProverContext(pk, r1cs, multi_exp_c=args.multi_exp_c, device=local_rank, shard_rank=rank, shard_count=world)
                         sp2 = ShardedProver(ctx2, dist, torch.device("cuda", local_rank))
@@ -443,8 +450,10 @@ def pmc_traffic(kernel, workload, logm, shards):
     try:
         d = json.load(open(os.path.join(ROOT, PMC_PROFILE)))
         cfg = d.get("config", {})
+        if d.get("kernel_sources_sha16") != kernel_sources_sha16():
+            return None, "%s (commit %s) was taken with other kernel sources than this build's: traffic not quoted" % (PMC_PROFILE, d.get("commit", "?"))
         if cfg.get("workload") == workload and cfg.get("logm") == logm and cfg.get("shards", 1) == shards:
-            return d["kernels"][kernel]["hbm_bytes_per_launch"], PMC_PROFILE
+            return d["kernels"][kernel]["hbm_bytes_per_launch"], "%s (PMC passes of commit %s, kernel sources %s)" % (PMC_PROFILE, d.get("commit", "?"), d.get("kernel_sources_sha16"))
         return None, "no PMC profile for this configuration (%s was taken at workload=%s, logm=%s, shards=%s)" % (
             PMC_PROFILE, cfg.get("workload"), cfg.get("logm"), cfg.get("shards", 1))
     except Exception:

@@ -685,6 +685,7 @@ struct zk_ctx {
     // (same window bits) the L-query's chunk pieces are folded into the H-query's bucket reduction -- one tail (finalize, heavy, group
     // reduce, tree sums) per proof less; zk_partials then carries the sum in Ht and the point at infinity in Lt.  ZK_NO_MERGE_HL=1: off.
     bool merge_hl = false;
+    bool cur_merge = false;                    // ... and whether the proof in flight does it (a small synchronous proof keeps two tails: see prove_enqueue)
     // tuning aids, read from the environment ONCE at context creation (never on the proving path)
     bool env_no_direct_h2d = false;            // ZK_NO_DIRECT_H2D: synchronous proofs stage the witness through pinned memory too
     int env_h_stream = -1;                     // ZK_H_STREAM=0 / 1 forces the H pipeline onto s_main / a borrowed tail stream (-1: by size)
@@ -1067,8 +1068,13 @@ static int prove_enqueue(zk_ctx *c, const uint64_t *witness, int canonical, int 
     ZK_TRY(c->mA.enqueue_reduce(t->share_A ? c->mW.view_for(t->offA, t->posA) : c->mA.view(), q, c->s_a, tail_lanes));    // tcc:488-495
     ZK_HIP(hipEventRecord(c->ev_a1, c->s_a));
     if (!t->share_L) { ZK_TRY(c->mL.enqueue_sort(c->d_w + (c->nIn + 1) + c->rL.lo, nullptr, c->rL.n(), 0, m, k, ws)); ZK_TRY(release()); }
+    // One synchronous proof below ~2^19 constraints is a latency chain: folded into the H-query's reduction the L-query's pieces double the
+    // serial additions per bucket at the very end of the proof, while a tail of its own runs early, beside the H pipeline (same-box A/B,
+    // tools/dev_sync_latency.py: 2^16 1.60 -> 1.65 ms, 2^18 3.38 -> 3.46 merged; 2^20 9.96 -> 9.94; pipelined 2^20: +2.8 % merged).  Sharded
+    // contexts fold whenever they can (their device-side partial sums carry Lt = infinity).
+    c->cur_merge = c->merge_hl && (c->cfg.shard_count > 1 || !c->latency_call || entries >= (1ull << 23));
     ZK_HIP(hipEventRecord(c->ev_l0, q));
-    if (c->merge_hl) {                                          // tcc:522-530; its chunk pieces wait for the H-query's bucket reduction (tcc:540: C = Ht + Lt)
+    if (c->cur_merge) {                                          // tcc:522-530; its chunk pieces wait for the H-query's bucket reduction (tcc:540: C = Ht + Lt)
         ZK_TRY(c->mL.enqueue_accumulate(t->share_L ? c->mW.view_for(t->offL) : c->mL.view(), q));
         ZK_HIP(hipEventRecord(c->ev_l1, q));
     } else {
@@ -1080,7 +1086,7 @@ static int prove_enqueue(zk_ctx *c, const uint64_t *witness, int canonical, int 
     if (!split_h) { ZK_TRY(h_pipeline()); ZK_TRY(release()); }
     else ZK_HIP(hipStreamWaitEvent(q, c->ev_sort_h, 0));
     ZK_TRY(c->mH.enqueue_accumulate(c->mH.view(), q));
-    ZK_TRY(c->mH.enqueue_tail(hs, tail_lanes, c->merge_hl ? &c->mL : nullptr));      // one bucket reduction for Ht + Lt
+    ZK_TRY(c->mH.enqueue_tail(hs, tail_lanes, c->cur_merge ? &c->mL : nullptr));     // one bucket reduction for Ht + Lt
     ZK_HIP(hipEventRecord(c->ev_h1, hs));
     return ZK_OK;
 }

@@ -270,7 +270,9 @@ inline void print_prover_blocks(const zk_timings &t, std::FILE *f = stdout) {
     leave(2, "Compute evaluation to B-query", t.b_query);                           // tcc:498-507
     leave(2, "Compute evaluation to H-query", t.h_query);                           // tcc:509-519
     leave(2, "Compute evaluation to L-query", t.l_query);                           // tcc:521-531
-    leave(1, "Compute the proof", (double)t.gpu_total - t.compute_h > 0 ? (double)t.gpu_total + t.host_finish : (double)t.host_finish);   // tcc:542
+    // what is left of the call after "Compute the polynomial H" (the phases overlap on the GPU: the block cannot exceed the call minus H)
+    const double after_h = (double)t.gpu_total - t.compute_h;
+    leave(1, "Compute the proof", (after_h > 0 ? after_h : 0.0) + t.host_finish);   // tcc:542
     leave(0, "Call to r1cs_gg_ppzksnark_zok_prover", total);                        // tcc:544
     std::fprintf(f, "* G1 elements in proof: 2\n* G2 elements in proof: 1\n* Proof size in bits: %d\n", 2 * 256 + 512);   // proof.print_size(), tcc:547 (uncompressed affine coordinates here)
 }

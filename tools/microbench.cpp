@@ -33,6 +33,8 @@ __global__ void k_rate(uint32_t *out, uint32_t seed, int iters) {
                 a0 = a0 + a1; a1 = a1 + a2; a2 = a2 + a3; a3 = a3 + a0;
             } else if (MODE == 6) {   // 64-bit add (v_add_co + v_addc)
                 c0 += c1; c1 += c2; c2 += c3; c3 += c0;
+            } else if (MODE == 7) {   // v_add_f64
+                d0 = d0 + d1; d1 = d1 + d2; d2 = d2 + d3; d3 = d3 + d0;
             }
         }
     }
@@ -78,13 +80,14 @@ int main() {
     printf("device: %s, CUs %d, clock %d MHz\n", p.name, p.multiProcessorCount, p.clockRate / 1000);
     const int grid = 256 * 8, block = 256, iters = 2000;
     uint32_t *out; CHECK(hipMalloc(&out, 4 * grid * block));
-    const char *names[] = {"v_mad_u64_u32", "v_mul_lo_u32", "v_mul_hi_u32", "v_mul_u32_u24+add", "v_fma_f64", "v_add_u32", "add_u64(2 instr)"};
-    float ms[7];
+    const char *names[] = {"v_mad_u64_u32", "v_mul_lo_u32", "v_mul_hi_u32", "v_mul_u32_u24+add", "v_fma_f64", "v_add_u32", "add_u64(2 instr)", "v_add_f64"};
+    float ms[8];
     ms[0] = time_kernel(k_rate<0>, grid, block, out, 12345u, iters); ms[1] = time_kernel(k_rate<1>, grid, block, out, 12345u, iters);
     ms[2] = time_kernel(k_rate<2>, grid, block, out, 12345u, iters); ms[3] = time_kernel(k_rate<3>, grid, block, out, 12345u, iters);
     ms[4] = time_kernel(k_rate<4>, grid, block, out, 12345u, iters); ms[5] = time_kernel(k_rate<5>, grid, block, out, 12345u, iters);
     ms[6] = time_kernel(k_rate<6>, grid, block, out, 12345u, iters);
-    for (int m = 0; m < 7; m++) {
+    ms[7] = time_kernel(k_rate<7>, grid, block, out, 12345u, iters);
+    for (int m = 0; m < 8; m++) {
         double ops = (double)grid * block * iters * 64.0;
         printf("%-20s %8.3f ms  %8.2f Tops/s  (%.2f lane-ops/clk/CU at 2.4 GHz)\n", names[m], ms[m], ops / ms[m] * 1e-9,
                ops / (ms[m] * 1e-3) / 2.4e9 / p.multiProcessorCount);
