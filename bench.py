@@ -143,6 +143,8 @@ def main():
         return r1cs, wm, pk, name, t_circuit, time.time() - t0
 
     r1cs, wm, pk, workload, t_circuit, t_keygen = make_workload(args.workload, args.logm)
+    if rank == 0:
+        print("[bench] circuit built in %.1f s, key generated in %.1f s" % (t_circuit, t_keygen), file=sys.stderr, flush=True)
     nC, m = r1cs.nC, r1cs.domain_size
     logm = m.bit_length() - 1
 
@@ -375,6 +377,8 @@ def main():
             "config": {"workload": workload,
                        "parallelism": ("msm-shard%d+allgather640B" % world) if shard else ("replicas%d" % world if world > 1 else "1gpu"),
                        "multi_exp_c": info["B"]["c"], "windows": W,
+                       "tables": {"bytes": info["table_bytes"], "planes": info["planes"],
+                                  "note": "window-multiple tables of the key; planes > 1 = memory-frugal layout (every planes-th window tabulated: the full tables did not fit the device)"},
                        "witness": WITNESS_NOTE[args.witness], "witness_bytes_h2d_per_proof": 0 if args.witness == "resident" else 32 * (r1cs.V + 1),
                        "inflight": max(1, args.inflight), "schedule": "one stream per context" if args.one_stream else "overlap (five streams per context)", "proofs_per_step": max(1, args.batch) if not shard else 1,
                        "batch_witnesses": ("identical" if args.batch_identical else "distinct") if args.batch > 1 else None, "device": devinfo},

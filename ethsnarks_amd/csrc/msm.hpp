@@ -104,6 +104,14 @@ inline uint32_t msm_machine_threads(uint32_t waves_per_simd) {
 
 struct MsmShape {
     uint32_t n = 0, c = 0, W = 0, nb = 0;
+    // Memory-frugal tables (a key whose W-fold window-multiple tables do not fit the device): the table keeps every S-th window only,
+    // T[r][k] = 2^(c S r) P_k for r < rows() = ceil(W / S), S = 2^plog.  Window w = S r + j then adds its digit times T[r][k] into bucket
+    // set ("plane") j, and the multi-exponentiation is sum_j 2^(c j) R_j over the S plane results (MsmWork::finish: c doublings per plane on
+    // the host).  The planes lie side by side exactly like the bucket sets of a batch: set = proof * S + j, and every kernel sees
+    // batch * S sets.  S = 1 is the default layout (one plane, W rows).
+    uint32_t plog = 0;
+    ZK_HD uint32_t planes() const { return 1u << plog; }
+    ZK_HD uint32_t rows() const { return (W + planes() - 1) >> plog; }
     uint32_t group = MSM_GROUP;     // buckets per running-sum thread
     ChunkRule chunk;
     uint32_t quad = 1;      // lanes per logical thread in the bucket-reduction kernels: 1, or 4 (Curve::*_q) for latency-bound sizes
@@ -133,7 +141,8 @@ struct MsmShape {
         return 2;
     }
     // batch: proofs per launch sequence the MSM will see (the latency / throughput switches below look at all their entries)
-    void set(uint32_t n_, uint32_t c_, uint32_t batch = 1) {
+    void set(uint32_t n_, uint32_t c_, uint32_t batch = 1, uint32_t plog_ = 0) {
+        plog = plog_;
         n = n_; c = c_ ? c_ : pick_c(n_, batch ? batch : 1);
         if (c < 2) c = 2;
         if (c > 20) c = 20;
@@ -167,8 +176,8 @@ struct MsmShape {
 // MSM's table ([w][remap_src] layout, scalar i) and this MSM covers scalars [remap_offset, remap_offset + n)
 struct SortView {
     const uint32_t *sorted = nullptr, *off = nullptr;   // off[b] = entries before bucket b, off[nb] = all entries
-    uint32_t nb = 0, entries_bound = 0;             // nb: buckets of the sort (batch x per-proof buckets); entries_bound: upper bound of sorted entries (batch x n_src x W)
-    uint32_t batch = 1;                             // proofs sorted together: bucket id = proof * (nb / batch) + digit bucket
+    uint32_t nb = 0, entries_bound = 0;             // nb: buckets of the sort (sets x per-set buckets); entries_bound: upper bound of sorted entries (batch x n_src x W)
+    uint32_t batch = 1;                             // bucket SETS sorted together (proofs x planes, MsmShape::plog): bucket id = set * (nb / sets) + digit bucket
     uint32_t remap_src = 0, remap_offset = 0;
     uint32_t remap_kbits = 0;                       // != 0: the entries are (window << kbits) | scalar instead of window * remap_src + scalar
     const uint32_t *remap_pos = nullptr;            // optional scalar index -> own base index (0xffffffff: absent); else i - remap_offset
@@ -182,7 +191,7 @@ struct MsmWork {
     MsmShape sh;
     SortShape ss;
     uint32_t max_batch = 1;                     // capacity: proofs per launch sequence the buffers are sized for
-    uint32_t cur_batch = 1;                     // ... and of the reduction in flight
+    uint32_t cur_batch = 1;                     // bucket SETS (proofs x planes) of the reduction in flight
     typename C::Affine *table = nullptr;        // [W][table_n] window multiples of the bases, resident for the context's life
     uint32_t table_n = 0;
     bool owns_table = true;                     // false: the table belongs to a DeviceTables entry shared by several contexts
@@ -191,7 +200,7 @@ struct MsmWork {
     uint32_t *off = nullptr, *sorted = nullptr;
     uint32_t *heavy_list = nullptr, *heavy_count = nullptr;
     typename C::XYZZ *pieces = nullptr, *bucket = nullptr, *partial_a = nullptr, *partial_b = nullptr;
-    typename C::XYZZ *host_result = nullptr;    // pinned, max_batch entries
+    typename C::XYZZ *host_result = nullptr;    // pinned, max_batch x planes entries
     typename C::XYZZ *dev_result = nullptr;     // optional: a device copy of the results as well, one every dev_result_pitch bytes (sharded provers exchange it with RCCL)
     size_t dev_result_pitch = 0;
     hipEvent_t ev_acc0 = nullptr, ev_acc1 = nullptr;   // bracket k_msm_accumulate (the dominant kernel) on its stream
@@ -202,7 +211,7 @@ struct MsmWork {
     // witness): take that shape (same c, W, buckets, chunk rule), size the reduction buffers for its entries,
     // and do not allocate sort buffers of its own.
     // sort_only: no table and no reduction buffers -- this object only sorts a scalar vector for others.
-    int alloc(uint32_t n, uint32_t c, typename C::Affine *shared_table = nullptr, const MsmShape *sort_like = nullptr, bool sort_only = false, uint32_t batch = 1);
+    int alloc(uint32_t n, uint32_t c, typename C::Affine *shared_table = nullptr, const MsmShape *sort_like = nullptr, bool sort_only = false, uint32_t batch = 1, uint32_t plog = 0);
     void release();
     // table <- window multiples of d_bases[0..n) (device pointer); once per context
     int precompute(const typename C::Affine *d_bases, uint32_t n, hipStream_t st);
@@ -225,11 +234,20 @@ struct MsmWork {
     const uint32_t *cur_off = nullptr;          // bucket offsets of the sort driving the current reduction
     uint32_t sort_batch = 1;                    // batch of the last enqueue_sort
     uint32_t sort_kbits = 0;                    // sort-only objects (the shared witness sort): entries carry (window << kbits) | scalar -- set by use_shift_payload()
-    void use_shift_payload() { uint32_t k = 1; while ((1ull << k) < table_n) k++; if (((uint64_t)sh.W << k) < (1ull << 31)) sort_kbits = k; }
-    SortView view() const { SortView v; v.sorted = sorted; v.off = off; v.batch = sort_batch; v.nb = sh.nb * sort_batch; v.entries_bound = (uint32_t)((uint64_t)table_n * sh.W * sort_batch); return v; }
+    void use_shift_payload() { uint32_t k = 1; while ((1ull << k) < table_n) k++; if (((uint64_t)sh.rows() << k) < (1ull << 31)) sort_kbits = k; }
+    SortView view() const { SortView v; v.sorted = sorted; v.off = off; v.batch = sort_batch << sh.plog; v.nb = sh.nb * v.batch; v.entries_bound = (uint32_t)((uint64_t)table_n * sh.W * sort_batch); return v; }
     // view for an MSM over scalars [offset, offset + n_dst) of THIS sort (its table has stride n_dst)
     SortView view_for(uint32_t offset, const uint32_t *pos = nullptr) const { SortView v = view(); v.remap_src = table_n; v.remap_offset = offset; v.remap_pos = pos; v.remap_kbits = sort_kbits; return v; }
-    typename C::XYZZ finish(uint32_t proof = 0) const { return C::canon(host_result[proof]); }   // device values are loose ([0, 2p)): normalise once
+    // device values are loose ([0, 2p)): normalise once.  Frugal tables: sum_j 2^(c j) R_j over the planes of the proof, Horner from the top plane
+    typename C::XYZZ finish(uint32_t proof = 0) const {
+        const uint32_t S = sh.planes();
+        typename C::XYZZ r = C::canon(host_result[(size_t)proof * S + (S - 1)]);
+        for (uint32_t j = S - 1; j-- > 0;) {
+            for (uint32_t d = 0; d < sh.c; d++) r = C::dbl(r);
+            r = C::add(r, C::canon(host_result[(size_t)proof * S + j]));
+        }
+        return S > 1 ? C::canon(r) : r;
+    }
 };
 
 }  // namespace zk

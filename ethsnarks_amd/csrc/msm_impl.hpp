@@ -12,7 +12,7 @@ namespace zk {
 template <class C>
 __global__ void __launch_bounds__(64, C::WAVES_PER_SIMD)
 k_msm_precompute(const typename C::Affine *__restrict__ bases, uint32_t n, uint32_t c, uint32_t W,
-                 typename C::Affine *__restrict__ table) {
+                 typename C::Affine *__restrict__ table) {        // c: doublings from one row to the next (window bits x planes), W: rows
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     const typename C::Affine p = bases[k];
@@ -55,7 +55,7 @@ static ZK_D fe msm_load_scalar(const fe *__restrict__ scalars, const uint32_t *_
 template <class C>
 __global__ void __launch_bounds__(SORT_THREADS)
 k_sort_count(const fe *__restrict__ scalars, const uint32_t *__restrict__ gather, uint32_t n, uint32_t batch, uint32_t stride, int canonical,
-             uint32_t c, uint32_t W, SortShape ss, uint32_t *__restrict__ counts) {
+             uint32_t c, uint32_t W, uint32_t plog, SortShape ss, uint32_t *__restrict__ counts) {
     __shared__ uint32_t cnt[SORT_MAX_CB];
     for (uint32_t k = threadIdx.x; k < ss.cb; k += blockDim.x) cnt[k] = 0;
     __syncthreads();
@@ -67,7 +67,7 @@ k_sort_count(const fe *__restrict__ scalars, const uint32_t *__restrict__ gather
         uint32_t carry = 0, neg;
         for (uint32_t w = 0; w < W; w++) {
             uint32_t d = msm_digit(s, w, c, carry, neg);
-            if (d) atomicAdd(&cnt[(p * nbp + d - 1) >> ss.fine_bits], 1u);
+            if (d) atomicAdd(&cnt[((((p << plog) | (w & ((1u << plog) - 1u))) * nbp) + d - 1) >> ss.fine_bits], 1u);      // bucket set = (proof, plane of the window)
         }
     }
     __syncthreads();
@@ -119,7 +119,7 @@ k_sort_binscan(const uint32_t *__restrict__ bin_total, uint32_t cb, uint32_t *__
 template <class C>
 __global__ void __launch_bounds__(SORT_THREADS)
 k_sort_partition(const fe *__restrict__ scalars, const uint32_t *__restrict__ gather, uint32_t n, uint32_t batch, uint32_t stride, int canonical,
-                 uint32_t c, uint32_t W, SortShape ss, const uint32_t *__restrict__ counts,
+                 uint32_t c, uint32_t W, uint32_t plog, SortShape ss, const uint32_t *__restrict__ counts,
                  const uint32_t *__restrict__ bin_base, uint2 *__restrict__ pairs, uint32_t kbits) {
     __shared__ uint32_t pos[SORT_MAX_CB];
     for (uint32_t k = threadIdx.x; k < ss.cb; k += blockDim.x) pos[k] = bin_base[k] + counts[(size_t)k * ss.groups + blockIdx.x];
@@ -133,11 +133,12 @@ k_sort_partition(const fe *__restrict__ scalars, const uint32_t *__restrict__ ga
         for (uint32_t w = 0; w < W; w++) {
             uint32_t d = msm_digit(s, w, c, carry, neg);
             if (!d) continue;
-            const uint32_t b = pr * nbp + d - 1;                        // (proof, bucket)
+            const uint32_t b = ((pr << plog) | (w & ((1u << plog) - 1u))) * nbp + d - 1;     // (proof, plane, bucket)
             uint32_t p = atomicAdd(&pos[b >> ss.fine_bits], 1u);
-            // payload: table index of 2^(cw) P_il (own sort: w n + il), or -- a sort that drives OTHER queries' tables -- (w << kbits) | il,
-            // which their accumulation kernels take apart with a shift and a mask instead of a division; sign in bit 31
-            uint2 e; e.x = (kbits ? (w << kbits) | il : w * n + il) | (neg << 31); e.y = b;
+            // payload: table index of 2^(cw) P_il (own sort: row * n + il, row = w >> plog), or -- a sort that drives OTHER queries' tables --
+            // (row << kbits) | il, which their accumulation kernels take apart with a shift and a mask instead of a division; sign in bit 31
+            const uint32_t row = w >> plog;
+            uint2 e; e.x = (kbits ? (row << kbits) | il : row * n + il) | (neg << 31); e.y = b;
             pairs[p] = e;
         }
     }
@@ -149,7 +150,7 @@ k_sort_partition(const fe *__restrict__ scalars, const uint32_t *__restrict__ ga
 template <class C>
 __global__ void __launch_bounds__(SORT_THREADS)
 k_sort_partition_staged(const fe *__restrict__ scalars, const uint32_t *__restrict__ gather, uint32_t n, uint32_t batch, uint32_t stride, int canonical,
-                        uint32_t c, uint32_t W, SortShape ss, const uint32_t *__restrict__ counts, const uint32_t *__restrict__ bin_total,
+                        uint32_t c, uint32_t W, uint32_t plog, SortShape ss, const uint32_t *__restrict__ counts, const uint32_t *__restrict__ bin_total,
                         const uint32_t *__restrict__ bin_base, uint2 *__restrict__ pairs, uint32_t kbits) {
     __shared__ uint2 stage[SORT_STAGE];
     __shared__ uint32_t lbase[SORT_MAX_CB], lcur[SORT_MAX_CB], gpos[SORT_MAX_CB], scan[SORT_THREADS];
@@ -180,8 +181,9 @@ k_sort_partition_staged(const fe *__restrict__ scalars, const uint32_t *__restri
         for (uint32_t w = 0; w < W; w++) {
             uint32_t d = msm_digit(sc, w, c, carry, neg);
             if (!d) continue;
-            const uint32_t b = pr * nbp + d - 1;                        // (proof, bucket)
-            uint2 e; e.x = (kbits ? (w << kbits) | il : w * n + il) | (neg << 31); e.y = b;     // payload as in k_sort_partition
+            const uint32_t b = ((pr << plog) | (w & ((1u << plog) - 1u))) * nbp + d - 1;     // (proof, plane, bucket)
+            const uint32_t row = w >> plog;
+            uint2 e; e.x = (kbits ? (row << kbits) | il : row * n + il) | (neg << 31); e.y = b;     // payload as in k_sort_partition
             stage[atomicAdd(&lcur[b >> ss.fine_bits], 1u)] = e;
         }
     }
@@ -412,35 +414,36 @@ k_msm_tree_sum(const typename C::XYZZ *__restrict__ in, uint32_t count, typename
 
 // -------------------------------------------------------------------------------------------------
 template <class C>
-int MsmWork<C>::alloc(uint32_t n, uint32_t c, typename C::Affine *shared_table, const MsmShape *sort_like, bool sort_only, uint32_t batch) {
+int MsmWork<C>::alloc(uint32_t n, uint32_t c, typename C::Affine *shared_table, const MsmShape *sort_like, bool sort_only, uint32_t batch, uint32_t plog) {
     max_batch = batch ? batch : 1;
-    if (sort_like) sh = *sort_like; else sh.set(n ? n : 1, c, max_batch);
+    if (sort_like) sh = *sort_like; else sh.set(n ? n : 1, c, max_batch, plog);
     sh.set_slots(sh.acc_pairs && C::WAVES_PER_SIMD_PAIRS != C::WAVES_PER_SIMD ? C::WAVES_PER_SIMD_PAIRS : C::WAVES_PER_SIMD);
-    const uint64_t B = max_batch;
-    if (sh.max_entries() * B >= (1ull << 31)) return fail_msg(ZK_ERR_ARG, "MSM too large: proofs * n * windows must stay below 2^31 (entry payload = table index | sign)");
-    if ((uint64_t)sh.nb * B > (uint64_t)SORT_MAX_CB * SORT_MAX_FB) return fail_msg(ZK_ERR_ARG, "batch too large: proofs * buckets exceeds the sort's 2^20 buckets");
+    const uint64_t B = max_batch, BS = (uint64_t)max_batch << sh.plog;         // proofs; bucket sets (proofs x planes)
+    if ((uint64_t)sh.n * sh.rows() >= (1ull << 31)) return fail_msg(ZK_ERR_ARG, "MSM too large: n * table rows must stay below 2^31 (entry payload = table index | sign)");
+    if (sh.max_entries() * B >= (1ull << 32) - 64) return fail_msg(ZK_ERR_ARG, "MSM too large: proofs * n * windows must stay below 2^32 (32-bit entry offsets)");
+    if ((uint64_t)sh.nb * BS > (uint64_t)SORT_MAX_CB * SORT_MAX_FB) return fail_msg(ZK_ERR_ARG, "batch too large: proofs * planes * buckets exceeds the sort's 2^20 buckets");
     const uint32_t G0 = sh.group, K = sh.nb < G0 ? sh.nb : G0, groups = sh.nb / K;
     if (sort_only) { owns_table = false; table_n = n; }
     else if (shared_table) { table = shared_table; owns_table = false; table_n = n; }
-    else ZK_HIP(hipMalloc(&table, sizeof(typename C::Affine) * (size_t)(n ? n : 1) * sh.W));
-    ss.set((uint32_t)(sh.n * B), (uint32_t)(sh.nb * B), sh.W);            // sized for a full batch (the bins of a smaller batch are re-derived per call)
+    else ZK_HIP(hipMalloc(&table, sizeof(typename C::Affine) * (size_t)(n ? n : 1) * sh.rows()));
+    ss.set((uint32_t)(sh.n * B), (uint32_t)(sh.nb * BS), sh.W);           // sized for a full batch (the bins of a smaller batch are re-derived per call)
     if (!sort_like) {
         ZK_HIP(hipMalloc(&pairs, sizeof(uint2) * sh.max_entries() * B));
         ZK_HIP(hipMalloc(&counts, sizeof(uint32_t) * ((size_t)SORT_MAX_CB * ss.groups + 1)));
         ZK_HIP(hipMalloc(&bin_total, sizeof(uint32_t) * (SORT_MAX_CB + 1)));
         ZK_HIP(hipMalloc(&bin_base, sizeof(uint32_t) * (SORT_MAX_CB + 1)));
         ZK_HIP(hipMalloc(&sorted, sizeof(uint32_t) * sh.max_entries() * B));
-        ZK_HIP(hipMalloc(&off, sizeof(uint32_t) * (sh.nb * B + 1)));
+        ZK_HIP(hipMalloc(&off, sizeof(uint32_t) * (sh.nb * BS + 1)));
     }
     if (sort_only) return ZK_OK;
-    const uint64_t n_pieces = sh.chunk.max_chunks(sh.max_entries() * B) + sh.nb * B + 1;
+    const uint64_t n_pieces = sh.chunk.max_chunks(sh.max_entries() * B) + sh.nb * BS + 1;
     ZK_HIP(hipMalloc(&heavy_list, sizeof(uint32_t) * (n_pieces / MSM_HEAVY + 2)));
     ZK_HIP(hipMalloc(&heavy_count, sizeof(uint32_t)));
     ZK_HIP(hipMalloc(&pieces, sizeof(typename C::XYZZ) * n_pieces));
-    ZK_HIP(hipMalloc(&bucket, sizeof(typename C::XYZZ) * sh.nb * B));
-    ZK_HIP(hipMalloc(&partial_a, sizeof(typename C::XYZZ) * ((size_t)groups * B + 1)));
-    ZK_HIP(hipMalloc(&partial_b, sizeof(typename C::XYZZ) * ((size_t)zk_div_up(groups, MSM_TREE / 4) * B + 1)));   // sized for 4 lanes per thread (the smaller fan-in), whichever a call uses
-    ZK_HIP(hipHostMalloc(&host_result, sizeof(typename C::XYZZ) * B, hipHostMallocDefault));
+    ZK_HIP(hipMalloc(&bucket, sizeof(typename C::XYZZ) * sh.nb * BS));
+    ZK_HIP(hipMalloc(&partial_a, sizeof(typename C::XYZZ) * ((size_t)groups * BS + 1)));
+    ZK_HIP(hipMalloc(&partial_b, sizeof(typename C::XYZZ) * ((size_t)zk_div_up(groups, MSM_TREE / 4) * BS + 1)));   // sized for 4 lanes per thread (the smaller fan-in), whichever a call uses
+    ZK_HIP(hipHostMalloc(&host_result, sizeof(typename C::XYZZ) * BS, hipHostMallocDefault));
     ZK_HIP(hipEventCreate(&ev_acc0)); ZK_HIP(hipEventCreate(&ev_acc1));
     return ZK_OK;
 }
@@ -460,7 +463,7 @@ template <class C>
 int MsmWork<C>::precompute(const typename C::Affine *d_bases, uint32_t n, hipStream_t st) {
     if (n > sh.n) return fail_msg(ZK_ERR_ARG, "MSM precompute: more bases than the shape was allocated for");
     table_n = n;
-    if (n) ZK_LAUNCH(k_msm_precompute<C>, zk_div_up(n, 64), 64, st, d_bases, n, sh.c, sh.W, table);
+    if (n) ZK_LAUNCH(k_msm_precompute<C>, zk_div_up(n, 64), 64, st, d_bases, n, sh.c << sh.plog, sh.rows(), table);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
@@ -470,16 +473,16 @@ int MsmWork<C>::enqueue_sort(const fe *scalars, const uint32_t *gather, uint32_t
     if (n != table_n || !sorted) return fail_msg(ZK_ERR_ARG, "MSM sort: scalar count differs from the table's base count");   // the table stride is the precompute-time n
     if (!batch || batch > max_batch) return fail_msg(ZK_ERR_ARG, "MSM sort: batch exceeds the capacity the context was created with");
     sort_batch = batch;
-    const uint32_t c = sh.c, W = sh.W, nb = sh.nb * batch;      // buckets of the whole batch
+    const uint32_t c = sh.c, W = sh.W, plog = sh.plog, nb = (sh.nb * batch) << plog;      // buckets of the whole batch, all planes
     SortShape sq = ss; sq.resize(n * batch ? n * batch : 1, nb);   // bins and workgroups for this call's scalars
-    ZK_LAUNCH_SYNC(k_sort_count<C>, sq.groups, SORT_THREADS, st, scalars, gather, n, batch, stride, canonical, c, W, sq, counts);
+    ZK_LAUNCH_SYNC(k_sort_count<C>, sq.groups, SORT_THREADS, st, scalars, gather, n, batch, stride, canonical, c, W, plog, sq, counts);
     ZK_LAUNCH_SYNC(k_sort_colscan<C>, sq.cb, SORT_THREADS, st, counts, sq.groups, bin_total);
     ZK_LAUNCH_SYNC(k_sort_binscan<C>, 1, SORT_THREADS, st, (const uint32_t *)bin_total, sq.cb, bin_base);
     if ((uint64_t)sq.per_group * W <= SORT_STAGE)
-        ZK_LAUNCH_SYNC(k_sort_partition_staged<C>, sq.groups, SORT_THREADS, st, scalars, gather, n, batch, stride, canonical, c, W, sq,
+        ZK_LAUNCH_SYNC(k_sort_partition_staged<C>, sq.groups, SORT_THREADS, st, scalars, gather, n, batch, stride, canonical, c, W, plog, sq,
                        (const uint32_t *)counts, (const uint32_t *)bin_total, (const uint32_t *)bin_base, pairs, sort_kbits);
     else
-    ZK_LAUNCH_SYNC(k_sort_partition<C>, sq.groups, SORT_THREADS, st, scalars, gather, n, batch, stride, canonical, c, W, sq,
+    ZK_LAUNCH_SYNC(k_sort_partition<C>, sq.groups, SORT_THREADS, st, scalars, gather, n, batch, stride, canonical, c, W, plog, sq,
                    (const uint32_t *)counts, (const uint32_t *)bin_base, pairs, sort_kbits);
     ZK_LAUNCH_SYNC(k_sort_fine<C>, sq.cb, SORT_FINE_THREADS, st, (const uint2 *)pairs, (const uint32_t *)bin_base, sq, nb, off, sorted);
     ZK_HIP(hipGetLastError());
@@ -521,12 +524,12 @@ int MsmWork<C>::launch_reduce(uint32_t K, uint32_t groups, hipStream_t st, const
 // first half of the reduction: the machine-filling accumulation of the sorted entries into chunk pieces, on `st`
 template <class C>
 int MsmWork<C>::enqueue_accumulate(const SortView &v, hipStream_t st) {
-    if (!v.sorted || !v.batch || v.batch > max_batch || v.nb != sh.nb * v.batch) return fail_msg(ZK_ERR_ARG, "MSM reduce: the driving sort has a different bucket count");   // a borrowed sort must have this MSM's buckets
-    cur_batch = v.batch;
+    if (!v.sorted || !v.batch || v.batch > (max_batch << sh.plog) || v.nb != sh.nb * v.batch) return fail_msg(ZK_ERR_ARG, "MSM reduce: the driving sort has a different bucket count");   // a borrowed sort must have this MSM's buckets
+    cur_batch = v.batch;                                        // bucket sets: proofs x planes
     const uint32_t nb = v.nb;                                   // buckets of all proofs of the batch
     // the entry count is only known on the device: launch for the most chunks it can give, threads past the end exit
     const uint64_t max_seg = sh.chunk.max_chunks(v.entries_bound);
-    if (max_seg + nb + 1 > sh.chunk.max_chunks(sh.max_entries() * max_batch) + (uint64_t)sh.nb * max_batch + 1) return fail_msg(ZK_ERR_ARG, "MSM reduce: the driving sort has more entries than this MSM was allocated for");
+    if (max_seg + nb + 1 > sh.chunk.max_chunks(sh.max_entries() * max_batch) + ((uint64_t)sh.nb * max_batch << sh.plog) + 1) return fail_msg(ZK_ERR_ARG, "MSM reduce: the driving sort has more entries than this MSM was allocated for");
     ZK_HIP(hipEventRecord(ev_acc0, st));
     bool pairs = false;
     if constexpr (C::WAVES_PER_SIMD_PAIRS != C::WAVES_PER_SIMD) pairs = sh.acc_pairs;      // (only a curve whose pairs form differs gets that kernel: G1)
@@ -553,7 +556,7 @@ int MsmWork<C>::enqueue_accumulate(const SortView &v, hipStream_t st) {
 template <class C>
 int MsmWork<C>::enqueue_tail(hipStream_t st_tail, uint32_t tail_lanes, MsmWork<C> *also) {
     if (!tail_pending) return fail_msg(ZK_ERR_ARG, "MSM tail: no accumulation is pending");
-    if (also && (!also->tail_pending || also->sh.nb != sh.nb || also->cur_batch != cur_batch)) return fail_msg(ZK_ERR_ARG, "MSM tail: the accumulation to fold in has other buckets or another batch");
+    if (also && (!also->tail_pending || also->sh.nb != sh.nb || also->sh.plog != sh.plog || also->cur_batch != cur_batch)) return fail_msg(ZK_ERR_ARG, "MSM tail: the accumulation to fold in has other buckets or another batch");
     tail_pending = false;
     const uint32_t G0 = sh.group, K = sh.nb < G0 ? sh.nb : G0, groups = sh.nb / K;   // running-sum groups per proof
     hipStream_t st = st_tail;
@@ -561,7 +564,7 @@ int MsmWork<C>::enqueue_tail(hipStream_t st_tail, uint32_t tail_lanes, MsmWork<C
     if (also) {
         also->tail_pending = false;
         ZK_HIP(hipStreamWaitEvent(st, also->ev_acc1, 0));
-        memset(also->host_result, 0, sizeof(typename C::XYZZ) * also->max_batch);        // infinity (ZZ = 0): its share is inside this MSM's result
+        memset(also->host_result, 0, sizeof(typename C::XYZZ) * ((size_t)also->max_batch << also->sh.plog));        // infinity (ZZ = 0): its share is inside this MSM's result
     }
     ZK_HIP(hipMemsetAsync(heavy_count, 0, sizeof(uint32_t), st));
     const uint32_t lanes = tail_lanes == 4 || tail_lanes == 1 ? tail_lanes : sh.quad;
@@ -570,7 +573,7 @@ int MsmWork<C>::enqueue_tail(hipStream_t st_tail, uint32_t tail_lanes, MsmWork<C
     typename C::XYZZ *cur = (tree_levels(groups, lanes) & 1) ? partial_b : partial_a;
     ZK_HIP(hipGetLastError());
     ZK_HIP(hipMemcpyAsync(host_result, cur, sizeof(typename C::XYZZ) * cur_batch, hipMemcpyDeviceToHost, st));
-    if (dev_result) {
+    if (dev_result && sh.plog == 0) {                           // (frugal tables: the planes are folded on the host, which then writes the device copy: zkhip.cpp)
         if (cur_batch == 1) ZK_HIP(hipMemcpyAsync(dev_result, cur, sizeof(typename C::XYZZ), hipMemcpyDeviceToDevice, st));
         else ZK_HIP(hipMemcpy2DAsync(dev_result, dev_result_pitch, cur, sizeof(typename C::XYZZ), sizeof(typename C::XYZZ), cur_batch, hipMemcpyDeviceToDevice, st));
     }

@@ -561,6 +561,8 @@ struct DeviceTables {
     uint32_t *posA = nullptr, *posB = nullptr;         // window position -> entry of this shard's query (0xffffffff: none); nullptr: position - offX
     uint32_t offA = 0, offB = 0, offL = 0;
     uint32_t cW = 0;                                   // window bits of the shared witness sort and of the tables it drives
+    uint32_t plog = 0;                                 // memory-frugal tables: every 2^plog-th window only (MsmShape::plog); 0 = all W windows
+    uint64_t table_bytes = 0, full_table_bytes = 0;    // what the four tables take, and what they would take with every window
     bool key_alive = true;                             // false once zk_pk_free has run: the last context to go takes the tables along
     int refs = 0;
     // device memory of the set; leaves the caller's current device as it found it (zk_pk_free runs this from wherever the
@@ -577,10 +579,13 @@ std::mutex g_tables_mu;
 std::vector<DeviceTables *> g_tables;
 
 template <class C>
-int build_table(typename C::Affine **out, const typename C::Affine *host_bases, uint32_t n, uint32_t cbits) {
+int build_table(typename C::Affine **out, const typename C::Affine *host_bases, uint32_t n, uint32_t cbits, uint32_t plog = 0) {
     MsmWork<C> tmp;                                      // only to own the expansion; its scratch is released again
     typename C::Affine *d_bases = nullptr;
-    int rc = tmp.alloc(n, cbits);
+    tmp.sh.set(n ? n : 1, cbits, 1, plog);
+    tmp.table_n = n;
+    int rc = ZK_OK;
+    if (hipMalloc(&tmp.table, sizeof(typename C::Affine) * (size_t)(n ? n : 1) * tmp.sh.rows()) != hipSuccess) { (void)hipGetLastError(); rc = fail_msg(ZK_ERR_NOMEM, "out of device memory for the window-multiple tables"); }
     if (rc == ZK_OK) rc = dev_upload(&d_bases, host_bases, n);
     if (rc == ZK_OK) rc = tmp.precompute(d_bases, n, nullptr);
     if (rc == ZK_OK && hipDeviceSynchronize() != hipSuccess) rc = fail(ZK_ERR_HIP, "k_msm_precompute failed");
@@ -760,15 +765,34 @@ static int ctx_build(zk_ctx *c, const zk_pk *pk, const zk_csr *A, const zk_csr *
             t->share_B = can_share && c->rB.n() >= dense;
             t->share_L = can_share && c->rL.n() >= dense;
             if ((int)t->share_A + (int)t->share_B + (int)t->share_L < 2) t->share_A = t->share_B = t->share_L = false;   // nothing to share
-            {   // make room for this key's tables (5 GB at 2^20, 20 GB at 2^22): idle table sets of other keys go first
-                const uint64_t need = 16ull * (64ull * ((uint64_t)c->rA.n() + c->rH.n() + c->rL.n()) + 128ull * c->rB.n());
-                size_t mem_free = 0, mem_total = 0;
-                while (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess && need + (8ull << 30) > mem_free && tables_evict_idle_locked(c->device)) {}
-            }
             auto window = [&](uint32_t n) { return t->cbits ? t->cbits : MsmShape::pick_c(n ? n : 1, t->max_batch); };
             t->cW = window(t->win_n);
             t->cA = t->share_A ? t->cW : window(c->rA.n()); t->cB = t->share_B ? t->cW : window(c->rB.n());
             t->cH = window(c->rH.n()); t->cL = t->share_L ? t->cW : window(c->rL.n());
+            {   // make room for this key's tables (5 GB at 2^20, 20 GB at 2^22): idle table sets on this device go first.  If the tables still
+                // do not fit they keep every 2nd, 4th, ... window only (MsmShape::plog: S bucket planes, c S doublings between table rows, the
+                // planes folded on the host) instead of failing the context: the reference's domain goes up to 2^28 (src/stubs.cpp:49-75),
+                // whose full tables would be 16 x the key.  ZK_TABLE_BUDGET=<bytes> (read here, at context creation) stands in for the free
+                // memory: a test aid, and a way to leave room for other tenants of the device.
+                auto rows_of = [&](uint32_t cb, uint32_t plog) { const uint32_t W = 254 / cb + 1, S = 1u << plog; return (uint64_t)((W + S - 1) >> plog); };
+                auto bytes_at = [&](uint32_t plog) {
+                    return 64ull * (rows_of(t->cA, plog) * c->rA.n() + rows_of(t->cH, plog) * c->rH.n() + rows_of(t->cL, plog) * c->rL.n()) + 128ull * rows_of(t->cB, plog) * c->rB.n();
+                };
+                t->full_table_bytes = bytes_at(0);
+                // what a context needs beside the tables: sort scratch (12 B per entry, two sorts), chunk pieces, polynomials, CSR -- about 16 B per
+                // entry of the four queries plus 8 GB of slack (the figure the eviction loop always kept)
+                const uint64_t entries = 15ull * ((uint64_t)c->rA.n() + c->rB.n() + c->rH.n() + c->rL.n()) * c->max_batch;
+                const uint64_t reserve = (8ull << 30) + 16ull * entries;
+                size_t mem_free = 0, mem_total = 0;
+                while (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess && t->full_table_bytes + reserve > mem_free && tables_evict_idle_locked(c->device)) {}
+                uint64_t budget = mem_free > reserve ? mem_free - reserve : 0;
+                if (const char *e = getenv("ZK_TABLE_BUDGET")) budget = strtoull(e, nullptr, 10);
+                // (proofs x planes x buckets must fit the sort's 2^20 bucket ids: MsmWork::alloc checks the same)
+                const uint32_t cmax = std::max(std::max(t->cA, t->cB), std::max(t->cH, t->cL));
+                auto sets_fit = [&](uint32_t plog) { return (((uint64_t)c->max_batch << plog) << (cmax - 1)) <= (1ull << 20); };
+                while (bytes_at(t->plog) > budget && t->plog < 4 && sets_fit(t->plog + 1)) t->plog++;
+                t->table_bytes = bytes_at(t->plog);
+            }
             int rc = dev_upload(&t->dA_idx, pk->a_idx.data() + c->rA.lo, c->rA.n());
             if (rc == ZK_OK) rc = dev_upload(&t->dB_idx, pk->b_idx.data() + c->rB.lo, c->rB.n());
             // window position -> shard entry: consecutive indices need no map (entry = position - off), else an explicit one
@@ -785,10 +809,10 @@ static int ctx_build(zk_ctx *c, const zk_pk *pk, const zk_csr *A, const zk_csr *
             if (rc == ZK_OK && t->share_A) rc = inverse(pk->a_idx, c->rA, &t->posA, &t->offA);
             if (rc == ZK_OK && t->share_B) rc = inverse(pk->b_idx, c->rB, &t->posB, &t->offB);
             t->offL = c->rL.n() ? nIn + 1 + c->rL.lo - t->win_lo : 0;
-            if (rc == ZK_OK) rc = build_table<G1>(&t->tA, pk->a_val.data() + c->rA.lo, c->rA.n(), t->cA);
-            if (rc == ZK_OK) rc = build_table<G1>(&t->tH, pk->H.data() + c->rH.lo, c->rH.n(), t->cH);
-            if (rc == ZK_OK) rc = build_table<G1>(&t->tL, pk->L.data() + c->rL.lo, c->rL.n(), t->cL);
-            if (rc == ZK_OK) rc = build_table<G2>(&t->tB, pk->b_val.data() + c->rB.lo, c->rB.n(), t->cB);
+            if (rc == ZK_OK) rc = build_table<G1>(&t->tA, pk->a_val.data() + c->rA.lo, c->rA.n(), t->cA, t->plog);
+            if (rc == ZK_OK) rc = build_table<G1>(&t->tH, pk->H.data() + c->rH.lo, c->rH.n(), t->cH, t->plog);
+            if (rc == ZK_OK) rc = build_table<G1>(&t->tL, pk->L.data() + c->rL.lo, c->rL.n(), t->cL, t->plog);
+            if (rc == ZK_OK) rc = build_table<G2>(&t->tB, pk->b_val.data() + c->rB.lo, c->rB.n(), t->cB, t->plog);
             if (rc != ZK_OK) return rc;
             g_tables.push_back(t);
             fresh.release();
@@ -800,11 +824,11 @@ static int ctx_build(zk_ctx *c, const zk_pk *pk, const zk_csr *A, const zk_csr *
     const DeviceTables *t = c->tables;
     const bool any_share = t->share_A || t->share_B || t->share_L;
     const uint32_t KB = c->max_batch;
-    if (any_share) { ZK_TRY(c->mW.alloc(t->win_n, t->cW, nullptr, nullptr, /*sort_only=*/true, KB)); c->mW.use_shift_payload(); }
-    ZK_TRY(c->mA.alloc(c->rA.n(), t->cA, t->tA, t->share_A ? &c->mW.sh : nullptr, false, KB));
-    ZK_TRY(c->mH.alloc(c->rH.n(), t->cH, t->tH, nullptr, false, KB));
-    ZK_TRY(c->mL.alloc(c->rL.n(), t->cL, t->tL, t->share_L ? &c->mW.sh : nullptr, false, KB));
-    ZK_TRY(c->mB.alloc(c->rB.n(), t->cB, t->tB, t->share_B ? &c->mW.sh : nullptr, false, KB));
+    if (any_share) { ZK_TRY(c->mW.alloc(t->win_n, t->cW, nullptr, nullptr, /*sort_only=*/true, KB, t->plog)); c->mW.use_shift_payload(); }
+    ZK_TRY(c->mA.alloc(c->rA.n(), t->cA, t->tA, t->share_A ? &c->mW.sh : nullptr, false, KB, t->plog));
+    ZK_TRY(c->mH.alloc(c->rH.n(), t->cH, t->tH, nullptr, false, KB, t->plog));
+    ZK_TRY(c->mL.alloc(c->rL.n(), t->cL, t->tL, t->share_L ? &c->mW.sh : nullptr, false, KB, t->plog));
+    ZK_TRY(c->mB.alloc(c->rB.n(), t->cB, t->tB, t->share_B ? &c->mW.sh : nullptr, false, KB, t->plog));
     ZK_TRY(c->cA.upload(A, V, KB)); ZK_TRY(c->cB.upload(B, V, KB)); ZK_TRY(c->cC.upload(C, V, KB));
     ZK_HIP(hipMalloc(&c->d_w, 32 * (size_t)(V + 1) * KB));
     // A | B | C polynomials of all proofs of a batch: [A: KB x m][B: KB x m][C: KB x m], one batched NTT launch per pass
@@ -812,7 +836,7 @@ static int ctx_build(zk_ctx *c, const zk_pk *pk, const zk_csr *A, const zk_csr *
     ZK_HIP(hipMalloc(&c->d_t, 3 * 32 * (size_t)m * KB));
     ZK_HIP(hipMalloc(&c->d_partials, sizeof(zk_partials) * KB));
     ZK_HIP(hipMemset(c->d_partials, 0, sizeof(zk_partials) * KB));                  // (a merged H + L tail never writes Lt: it stays the point at infinity)
-    c->merge_hl = c->rH.n() && c->rL.n() && c->mH.sh.nb == c->mL.sh.nb && !getenv("ZK_NO_MERGE_HL");
+    c->merge_hl = c->rH.n() && c->rL.n() && c->mH.sh.nb == c->mL.sh.nb && c->mH.sh.plog == c->mL.sh.plog && !getenv("ZK_NO_MERGE_HL");
     if (G > 1) {      // sharded provers exchange the device copy of their partial sums (zk_prove_collect_device)
         c->mA.dev_result = (G1::XYZZ *)(c->d_partials + offsetof(zk_partials, At)); c->mB.dev_result = (G2::XYZZ *)(c->d_partials + offsetof(zk_partials, Bt));
         c->mH.dev_result = (G1::XYZZ *)(c->d_partials + offsetof(zk_partials, Ht));
@@ -1105,6 +1129,13 @@ static int prove_collect_impl(zk_ctx *c, zk_partials *out, zk_timings *tm) {    
     if (out) for (uint32_t p = 0; p < c->cur_batch; p++) {      // out: cur_batch records
         store_xyzz(out[p].At, c->mA.finish(p)); store_xyzz(out[p].Bt, c->mB.finish(p));
         store_xyzz(out[p].Ht, c->mH.finish(p)); store_xyzz(out[p].Lt, c->mL.finish(p));
+    } else if (c->tables->plog) {                               // device copy of a sharded context with frugal tables: the planes are folded here, on the host
+        std::vector<zk_partials> parts(c->cur_batch);
+        for (uint32_t p = 0; p < c->cur_batch; p++) {
+            store_xyzz(parts[p].At, c->mA.finish(p)); store_xyzz(parts[p].Bt, c->mB.finish(p));
+            store_xyzz(parts[p].Ht, c->mH.finish(p)); store_xyzz(parts[p].Lt, c->mL.finish(p));
+        }
+        ZK_HIP(hipMemcpy(c->d_partials, parts.data(), sizeof(zk_partials) * c->cur_batch, hipMemcpyHostToDevice));
     }
     if (tm) {
         memset(tm, 0, sizeof(*tm));
@@ -1268,6 +1299,12 @@ extern "C" int zk_ctx_info(const zk_ctx *c, uint32_t info[16]) try {
     const MsmShape *sh[4] = {&c->mA.sh, &c->mB.sh, &c->mH.sh, &c->mL.sh};
     for (int i = 0; i < 4; i++) { info[3 * i] = sh[i]->c; info[3 * i + 1] = sh[i]->W; info[3 * i + 2] = sh[i]->nb; }
     info[12] = c->tables->share_A; info[13] = c->tables->share_B; info[14] = c->tables->share_L; info[15] = c->m;
+    return ZK_OK;
+} ZK_GUARD
+// the window-multiple tables of the context: {bytes they take, bytes all W windows would take, planes S (1 = every window is tabulated), table rows of the B-query}
+extern "C" int zk_ctx_table_info(const zk_ctx *c, uint64_t info[4]) try {
+    if (!c || !info) return fail(ZK_ERR_ARG, "null argument");
+    info[0] = c->tables->table_bytes; info[1] = c->tables->full_table_bytes; info[2] = 1ull << c->tables->plog; info[3] = c->mB.sh.rows();
     return ZK_OK;
 } ZK_GUARD
 extern "C" int zk_prove_collect(zk_ctx *ctx, zk_partials *out, zk_timings *t) try {
@@ -1861,7 +1898,9 @@ static int msm_host(const uint64_t *bases, const uint64_t *scalars, uint32_t n, 
     MsmWork<C> work;
     int rc = dev_upload(&d_bases, (const typename C::Affine *)bases, n);
     if (rc == ZK_OK) rc = dev_upload(&d_scalars, (const fe *)scalars, n);
-    if (rc == ZK_OK) rc = work.alloc(n, cbits);
+    uint32_t plog = 0;                                      // test aid: the frugal table layout (every 2^plog-th window, 2^plog bucket planes) at kernel level
+    if (const char *e = getenv("ZK_TEST_PLANES_LOG")) plog = (uint32_t)atoi(e) & 7u;
+    if (rc == ZK_OK) rc = work.alloc(n, cbits, nullptr, nullptr, false, 1, plog);
     if (rc == ZK_OK) rc = work.precompute(d_bases, n, nullptr);
     if (rc == ZK_OK) rc = work.enqueue(d_scalars, nullptr, n, 0, nullptr, nullptr);
     if (rc == ZK_OK && hipDeviceSynchronize() != hipSuccess) rc = fail(ZK_ERR_HIP, "MSM kernels failed");

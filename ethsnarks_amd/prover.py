@@ -66,7 +66,7 @@ EXPORTS = [
     "zk_wplan_create", "zk_wplan_create_hinted", "zk_wplan_solve", "zk_wplan_free", "zk_dev_alloc", "zk_dev_free", "zk_dev_upload", "zk_dev_download",
     "zk_chain_submit", "zk_chain_device", "zk_h_from_chains_submit", "zk_h_device", "zk_chain_wait", "zk_prove_submit_with_h", "zk_prove_submit_defer_h", "zk_prove_submit_h", "zk_prove_abort",
     "zk_prove_submit_pinned", "zk_prove_batch_submit_pinned", "zk_host_alloc", "zk_host_free", "zk_host_register", "zk_host_unregister",
-    "zk_prove_submit_resident", "zk_prove_stage", "zk_prove_stage_pinned", "zk_prove_submit_staged", "zk_ctx_info", "zk_ctx_partials_device", "zk_prove_collect_device", "zk_prove_combine_device", "zk_launch_count", "zk_profile_begin", "zk_profile_end", "zk_device_info", "zk_device_pci_bus_id",
+    "zk_prove_submit_resident", "zk_prove_stage", "zk_prove_stage_pinned", "zk_prove_submit_staged", "zk_ctx_info", "zk_ctx_table_info", "zk_ctx_partials_device", "zk_prove_collect_device", "zk_prove_combine_device", "zk_launch_count", "zk_profile_begin", "zk_profile_end", "zk_device_info", "zk_device_pci_bus_id",
     "zk_verify",
     "zk_ntt", "zk_witness_map", "zk_msm_g1", "zk_msm_g2", "zk_field_mul", "zk_fr_convert",
 ]
@@ -433,6 +433,9 @@ class ProverContext:
         v = list(a)
         d = {q: {"c": v[3 * i], "W": v[3 * i + 1], "buckets": v[3 * i + 2]} for i, q in enumerate("ABHL")}
         d.update(share_A=bool(v[12]), share_B=bool(v[13]), share_L=bool(v[14]), m=v[15])
+        t = (C.c_uint64 * 4)()
+        _check(_lib.zk_ctx_table_info(self._h, t))                      # planes > 1: memory-frugal tables (every planes-th window tabulated)
+        d.update(table_bytes=int(t[0]), full_table_bytes=int(t[1]), planes=int(t[2]), table_rows_B=int(t[3]))
         return d
 
     def collect(self):

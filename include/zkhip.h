@@ -251,6 +251,12 @@ int zk_prove_submit_staged(zk_ctx *ctx);
 /* info[3q .. 3q+2] = {window bits c, windows W, buckets 2^(c-1)} of query q = A, B, H, L; info[12..14] = the A-, B-, L-query
  * ride the shared witness sort; info[15] = domain size m */
 int zk_ctx_info(const zk_ctx *ctx, uint32_t info[16]);
+/* the window-multiple tables of the context's key shard: info = {bytes they take, bytes they would take with every window tabulated,
+ * planes S, table rows of the B-query}.  S = 1 is the default layout (all W windows: 16 x the key).  When that does not fit the device --
+ * the reference's domain goes up to 2^28, src/stubs.cpp:49-75 -- zk_ctx_create keeps every S-th window only (S = 2, 4, 8, 16) and proves
+ * with S bucket planes instead of failing; the proof bytes are the same.  ZK_TABLE_BUDGET=<bytes> in the environment at context creation
+ * caps the tables below the free device memory. */
+int zk_ctx_table_info(const zk_ctx *ctx, uint64_t info[4]);
 
 /* inputs: nIn Fr elements = witness[1..nIn] (Montgomery unless canonical); returns the JSON length
  * (excluding NUL) through *len; ZK_ERR_BUFFER if cap is too small (len still set) */

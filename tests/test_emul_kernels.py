@@ -393,3 +393,59 @@ def test_witness_plan_with_inverse_and_nonzero_hints(zk, oracle):
     assert bad.solve(buf.ptr, k) > 0
     bad.close(); buf.free()
 
+
+
+@pytest.mark.parametrize("plog", [1, 2])
+def test_msm_frugal_tables_planes(zk, oracle, monkeypatch, plog):
+    """memory-frugal table layout at kernel level (MsmShape::plog): every 2^plog-th window tabulated, 2^plog bucket planes, planes
+    folded on the host -- the same group element as the full tables (ZK_TEST_PLANES_LOG is a test aid of zk_msm_g1 / zk_msm_g2)"""
+    monkeypatch.setenv("ZK_TEST_PLANES_LOG", str(plog))
+    for g2 in (False, True):
+        for n, c in [(1, 0), (7, 0), (300, 4), (1000, 9)]:
+            sc = rand_scalars(n, n + 3, ones_every=5, zeros_every=7)
+            if n > 20:
+                sc[11] = F.FR - 1; sc[12] = 2; sc[13] = 1 << 253
+            bases = oracle.batch_mul(F.fr_to_mont(rand_scalars(n, 98)), g2=g2)
+            if n > 30:
+                bases[20] = 0; bases[21] = bases[22]
+            s = F.fr_to_mont(sc)
+            assert np.array_equal(zk.msm(bases, s, g2=g2, c=c), oracle.msm(bases, s, g2=g2)), (g2, n, c)
+
+
+@pytest.mark.parametrize("frac", [2, 4, 16])
+def test_prove_with_a_table_budget_below_the_full_tables(zk, oracle, monkeypatch, frac):
+    """ZK_TABLE_BUDGET below the W-fold tables: zk_ctx_create keeps every S-th window instead of failing (S = planes), the proof bytes do
+    not change -- single proofs, a batch, the merged H + L tail, and a sharded context's device-side partial sums"""
+    r, w = R.synthetic_chain(254, 1)
+    wm = F.fr_to_mont(w)
+    pk_o, _ = oracle.keygen(r, seed=31)
+    expect = oracle.prove(pk_o, r, wm)[0]
+    pk = zk.ProvingKey.from_parts(**pk_o.parts())
+    full = zk.ProverContext(pk, r)
+    fi = full.info()
+    assert fi["planes"] == 1 and fi["table_bytes"] == fi["full_table_bytes"]
+    full.close(); pk.close()
+    monkeypatch.setenv("ZK_TABLE_BUDGET", str(fi["full_table_bytes"] // frac))
+    pk = zk.ProvingKey.from_parts(**pk_o.parts())          # a new key object: the table cache is per key
+    ctx = zk.ProverContext(pk, r, max_batch=3)
+    info = ctx.info()
+    assert info["planes"] >= 2 and info["table_bytes"] <= fi["full_table_bytes"] // frac + 4096 * 320 or info["planes"] == 16
+    assert info["table_rows_B"] == -(-info["B"]["W"] // info["planes"])
+    assert zk.prove(ctx, wm) == expect
+    _, w2 = R.synthetic_chain(254, 1, seed=R.SEED_DEFAULT + 1)
+    wm2 = F.fr_to_mont(w2)
+    assert zk.prove_batch(ctx, np.stack([wm, wm2, wm])) == [expect, oracle.prove(pk_o, r, wm2)[0], expect]
+    ctx.close()
+    parts = []
+    monkeypatch.setenv("ZK_TABLE_BUDGET", str(fi["full_table_bytes"] // (3 * frac)))      # (a shard holds a third of every table)
+    for k in range(3):                                     # sharded contexts: the device copy of the partial sums is written after the host fold
+        sc = zk.ProverContext(pk, r, shard_rank=k, shard_count=3)
+        assert sc.info()["planes"] >= 2
+        sc.submit(wm); sc.collect_device()
+        import ctypes as C
+        buf = np.zeros(80, dtype=np.uint64)
+        assert zk._lib.zk_dev_download(buf.ctypes.data_as(C.c_void_p), C.c_void_p(sc.partials_device_ptr()), C.c_size_t(640)) == 0
+        parts.append(buf)
+        last = sc
+    assert zk.proof_to_json(last.prove_combine(np.stack(parts)), wm[1:2]) == expect
+    pk.close()

@@ -417,6 +417,48 @@ def test_config2_chain_2pow18_gpu_keygen(hip, oracle, tmp_path):
     assert expect == oracle.proof_from_trapdoor(r, wm, oracle.toxic_from_seed(18))  # closed form: independent of the .raw codec too
 
 
+@pytest.mark.parametrize("g2", [False, True], ids=["G1", "G2"])
+def test_msm_frugal_table_planes_vs_oracle(hip, oracle, monkeypatch, g2):
+    """the memory-frugal table layout at kernel level (every 2^plog-th window tabulated, 2^plog bucket planes folded on the host)"""
+    for plog, n, c in [(1, 1000, 0), (2, 20000, 0), (1, 1 << 16, 0), (3, 5000, 11)]:
+        monkeypatch.setenv("ZK_TEST_PLANES_LOG", str(plog))
+        sc = rand_scalars(n, n + 5, ones_every=9, zeros_every=11)
+        bases = tiled_bases(oracle, n, g2=g2)
+        s = F.fr_to_mont(sc)
+        assert np.array_equal(hip.msm(bases, s, g2=g2, c=c), oracle.msm(bases, s, g2=g2)), (plog, n, c)
+
+
+def test_prove_2pow18_with_a_quarter_of_the_table_memory(hip, oracle, monkeypatch):
+    """a key whose W-fold window-multiple tables do not fit (the reference's domain goes up to 2^28, src/stubs.cpp:49-75): with the table
+    budget forced to a quarter of the full tables zk_ctx_create tabulates every 4th window and proves with four bucket planes instead of
+    failing; the proof equals the oracle's and the closed form, one at a time and pipelined through the staged pinned-witness path"""
+    logm = 18
+    r, w = R.synthetic_chain((1 << logm) - 2, 1)
+    wm = F.fr_to_mont(w)
+    pk, _ = hip.keygen(r, seed=R.SEED_DEFAULT)
+    full = hip.ProverContext(pk, r)
+    fi = full.info()
+    expect = hip.prove(full, wm)
+    full.close()
+    assert fi["planes"] == 1 and expect == oracle.prove(oracle.pk_from_parts(pk.parts()), r, wm)[0]
+    assert expect == oracle.proof_from_trapdoor(r, wm, oracle.toxic_from_seed(R.SEED_DEFAULT))
+    parts = pk.parts()
+    pk.close()                                                   # drops the full tables (they belong to the key)
+    monkeypatch.setenv("ZK_TABLE_BUDGET", str(fi["full_table_bytes"] // 4))
+    pk2 = hip.ProvingKey.from_parts(**parts)
+    ctx = hip.ProverContext(pk2, r)
+    info = ctx.info()
+    assert info["planes"] == 4 and info["table_bytes"] <= fi["full_table_bytes"] // 4 and info["table_rows_B"] == -(-info["B"]["W"] // 4)
+    assert hip.prove(ctx, wm) == expect
+    other = hip.ProverContext(pk2, r)                            # shares the frugal tables; two proofs in flight
+    assert other.info()["planes"] == 4
+    ctx.submit(wm); other.submit(wm)
+    for c in (ctx, other):
+        part, _ = c.collect()
+        assert hip.proof_to_json(c.prove_combine(part), wm[1:2]) == expect
+    ctx.close(); other.close(); pk2.close()
+
+
 def test_staged_upload_double_buffering(hip, oracle):
     """zk_prove_stage / zk_prove_submit_staged: the next witness is copied while a proof is in flight; proofs unchanged"""
     r, w = R.random_r1cs(900, 2, seed=41)
