@@ -62,16 +62,39 @@ void zk::launch_post(hipStream_t st) {
 }
 extern "C" uint64_t zk_launch_count(void) { return g_launches.load(); }
 #ifdef ZK_EXP_MARGINAL
-bool zk::exp_skip(const char *name) {
-    static const char *list = getenv("ZK_EXP_SKIP");
-    static const uint64_t after = getenv("ZK_EXP_SKIP_AFTER") ? strtoull(getenv("ZK_EXP_SKIP_AFTER"), nullptr, 10) : 150;
-    if (!list || !*list || g_launches.load(std::memory_order_relaxed) < after) return false;
+// The launches of one bucket sort are producers and consumers of each other's buffers IN PLACE: k_sort_colscan scans the count matrix that
+// k_sort_count wrote, k_sort_binscan / k_sort_partition / k_sort_fine read what the scans left.  Dropping a producer while its consumer still runs
+// makes the consumer work on the previous proof's ALREADY SCANNED state -- round 3's "no sort_count,partition" experiment (variants/marg2.sh) let
+// k_sort_colscan scan scanned counts a second time, k_sort_binscan turn the inflated bin totals into bin bases far beyond the entry count, and
+// k_sort_fine then load `pairs[e]` (and store `sorted[...]`) at those bases, past the end of both allocations: a device fault, whose text the script
+// had sent to /dev/null.  A skip list must therefore name ALL FIVE sort kernels or none; anything else is refused here (nothing is skipped, and
+// the refusal is printed once), as is a list that drops k_msm_bucket_finalize / k_msm_heavy but keeps the accumulation they depend on being fresh
+// -- that one is harmless (stale pieces of the same witness) and stays allowed.
+static bool exp_list_has(const char *list, const char *name) {
     for (const char *p = list; *p;) {
         const char *e = strchr(p, ';'); const size_t n = e ? (size_t)(e - p) : strlen(p);
         if (n && std::string(name).find(std::string(p, n)) != std::string::npos) return true;
         p += n + (e ? 1 : 0);
     }
     return false;
+}
+bool zk::exp_skip(const char *name) {
+    static const char *list = getenv("ZK_EXP_SKIP");
+    static const uint64_t after = getenv("ZK_EXP_SKIP_AFTER") ? strtoull(getenv("ZK_EXP_SKIP_AFTER"), nullptr, 10) : 150;
+    static const bool valid = [] {
+        if (!list || !*list) return true;
+        const char *chain[] = {"k_sort_count<C>", "k_sort_colscan<C>", "k_sort_binscan<C>", "k_sort_partition_staged<C>", "k_sort_partition<C>", "k_sort_fine<C>"};
+        int hit = 0;
+        for (const char *k : chain) hit += exp_list_has(list, k);
+        if (hit != 0 && hit != 6) {
+            fprintf(stderr, "zkhip (measurement build): ZK_EXP_SKIP=\"%s\" drops part of the bucket-sort chain: its kernels scan each other's buffers in place, "
+                            "a consumer without its producer indexes past its allocations.  Name all of k_sort_ or none.  Nothing is skipped.\n", list);
+            return false;
+        }
+        return true;
+    }();
+    if (!valid || !list || !*list || g_launches.load(std::memory_order_relaxed) < after) return false;
+    return exp_list_has(list, name);
 }
 #endif
 extern "C" int zk_profile_begin(void) try {
@@ -695,6 +718,8 @@ struct zk_ctx {
     bool env_no_direct_h2d = false;            // ZK_NO_DIRECT_H2D: synchronous proofs stage the witness through pinned memory too
     int env_h_stream = -1;                     // ZK_H_STREAM=0 / 1 forces the H pipeline onto s_main / a borrowed tail stream (-1: by size)
     char env_h_borrow = 0;                     // ZK_H_BORROW=a / l / b picks the borrowed stream (0: by entry point)
+    char env_hl_tail = 0;                      // ZK_HL_TAIL=l / a: the merged H + L bucket reduction on the L- / A-tail stream instead of the H pipeline's (0)
+    int env_b_tail_lanes = 0;                  // ZK_B_TAIL_LANES=1 / 4: lanes per point operation of the B-query's (G2) bucket reduction (0: by size / entry point)
     hipEvent_t ev_sort = nullptr;              // a finished bucket sort on s_main releases its accumulation on s_acc
     hipEvent_t ev_start = nullptr, ev_w = nullptr, ev_h = nullptr, ev_a0 = nullptr, ev_a1 = nullptr, ev_b0 = nullptr, ev_b1 = nullptr,
                ev_l0 = nullptr, ev_l1 = nullptr, ev_h1 = nullptr, ev_h0 = nullptr;
@@ -871,6 +896,8 @@ static int ctx_build(zk_ctx *c, const zk_pk *pk, const zk_csr *A, const zk_csr *
     c->env_no_direct_h2d = getenv("ZK_NO_DIRECT_H2D") != nullptr;
     if (const char *e = getenv("ZK_H_STREAM")) c->env_h_stream = e[0] == '1' ? 1 : 0;
     if (const char *e = getenv("ZK_H_BORROW")) c->env_h_borrow = e[0];
+    if (const char *e = getenv("ZK_HL_TAIL")) c->env_hl_tail = e[0];
+    if (const char *e = getenv("ZK_B_TAIL_LANES")) c->env_b_tail_lanes = atoi(e);
     const char *serial = getenv("ZK_SERIAL");
     c->serial = (serial && serial[0] == '1') || c->cfg.schedule == ZK_SCHED_ONE_STREAM;
     const char *split = getenv("ZK_SPLIT_STREAMS");
@@ -1085,7 +1112,7 @@ static int prove_enqueue(zk_ctx *c, const uint64_t *witness, int canonical, int 
     if (!t->share_B) { ZK_TRY(c->mB.enqueue_sort(c->d_w, c->dB_idx, c->rB.n(), 0, m, k, ws)); ZK_TRY(release()); }
     if (split_h) ZK_TRY(h_pipeline());
     ZK_HIP(hipEventRecord(c->ev_b0, q));
-    ZK_TRY(c->mB.enqueue_reduce(t->share_B ? c->mW.view_for(t->offB, t->posB) : c->mB.view(), q, c->s_b, tail_lanes));    // tcc:499-506
+    ZK_TRY(c->mB.enqueue_reduce(t->share_B ? c->mW.view_for(t->offB, t->posB) : c->mB.view(), q, c->s_b, c->env_b_tail_lanes ? (uint32_t)c->env_b_tail_lanes : tail_lanes));    // tcc:499-506
     ZK_HIP(hipEventRecord(c->ev_b1, c->s_b));
     if (!t->share_A) { ZK_TRY(c->mA.enqueue_sort(c->d_w, c->dA_idx, c->rA.n(), 0, m, k, ws)); ZK_TRY(release()); }
     ZK_HIP(hipEventRecord(c->ev_a0, q));
@@ -1110,8 +1137,10 @@ static int prove_enqueue(zk_ctx *c, const uint64_t *witness, int canonical, int 
     if (!split_h) { ZK_TRY(h_pipeline()); ZK_TRY(release()); }
     else ZK_HIP(hipStreamWaitEvent(q, c->ev_sort_h, 0));
     ZK_TRY(c->mH.enqueue_accumulate(c->mH.view(), q));
-    ZK_TRY(c->mH.enqueue_tail(hs, tail_lanes, c->cur_merge ? &c->mL : nullptr));     // one bucket reduction for Ht + Lt
-    ZK_HIP(hipEventRecord(c->ev_h1, hs));
+    hipStream_t ts = hs;                                        // stream of the (merged) H tail
+    if (c->cur_merge && !c->serial && c->env_hl_tail) ts = c->env_hl_tail == 'l' ? c->s_l : c->env_hl_tail == 'a' ? c->s_a : hs;
+    ZK_TRY(c->mH.enqueue_tail(ts, tail_lanes, c->cur_merge ? &c->mL : nullptr));     // one bucket reduction for Ht + Lt
+    ZK_HIP(hipEventRecord(c->ev_h1, ts));
     return ZK_OK;
 }
 

@@ -148,15 +148,28 @@ enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDevi
 enum { hipStreamNonBlocking = 1, hipHostMallocDefault = 0 };
 inline const char *hipGetErrorString(hipError_t e) { return e ? "emul error" : "ok"; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
-inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
-inline hipError_t hipSetDevice(int) { return hipSuccess; }
-inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
+// device model: ZK_EMUL_DEVICES "devices" (default 1) that share the host's memory; what the emulator keeps per device is what the multi-device
+// host logic can get wrong -- the calling thread's CURRENT device, the free memory hipMemGetInfo reports, and a count of allocations made while
+// the device was current (tests/test_emul_kernels.py drives the three hooks below through ctypes)
+namespace zk_emul {
+constexpr int MAX_DEV = 8;
+inline int g_devices = [] { const char *e = getenv("ZK_EMUL_DEVICES"); const int n = e ? atoi(e) : 1; return n < 1 ? 1 : n > MAX_DEV ? MAX_DEV : n; }();
+inline thread_local int t_device = 0;
+inline size_t g_free[MAX_DEV] = {(size_t)1 << 40, (size_t)1 << 40, (size_t)1 << 40, (size_t)1 << 40, (size_t)1 << 40, (size_t)1 << 40, (size_t)1 << 40, (size_t)1 << 40};
+inline std::atomic<uint64_t> g_allocs[MAX_DEV];
+}
+extern "C" __attribute__((used, visibility("default"))) inline void zk_emul_set_free_mem(int dev, size_t bytes) { if (dev >= 0 && dev < zk_emul::MAX_DEV) zk_emul::g_free[dev] = bytes; }
+extern "C" __attribute__((used, visibility("default"))) inline int zk_emul_current_device(void) { return zk_emul::t_device; }
+extern "C" __attribute__((used, visibility("default"))) inline uint64_t zk_emul_alloc_count(int dev) { return dev >= 0 && dev < zk_emul::MAX_DEV ? zk_emul::g_allocs[dev].load() : 0; }
+inline hipError_t hipGetDeviceCount(int *n) { *n = zk_emul::g_devices; return hipSuccess; }
+inline hipError_t hipSetDevice(int d) { if (d < 0 || d >= zk_emul::g_devices) return hipErrorInvalidValue; zk_emul::t_device = d; return hipSuccess; }
+inline hipError_t hipGetDevice(int *d) { *d = zk_emul::t_device; return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
-template <class T> hipError_t hipMalloc(T **p, size_t n) { *p = (T *)calloc(n ? n : 1, 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+template <class T> hipError_t hipMalloc(T **p, size_t n) { zk_emul::g_allocs[zk_emul::t_device]++; *p = (T *)calloc(n ? n : 1, 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
 template <class T> hipError_t hipHostMalloc(T **p, size_t n, unsigned = 0) { *p = (T *)calloc(n ? n : 1, 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
-inline hipError_t hipMemGetInfo(size_t *f, size_t *t) { *f = *t = (size_t)1 << 40; return hipSuccess; }
+inline hipError_t hipMemGetInfo(size_t *f, size_t *t) { *f = zk_emul::g_free[zk_emul::t_device]; *t = (size_t)1 << 40; return hipSuccess; }
 enum { hipHostRegisterDefault = 0 };
 inline hipError_t hipHostRegister(void *, size_t, unsigned) { return hipSuccess; }
 inline hipError_t hipHostUnregister(void *) { return hipSuccess; }

@@ -449,3 +449,59 @@ def test_prove_with_a_table_budget_below_the_full_tables(zk, oracle, monkeypatch
         last = sc
     assert zk.proof_to_json(last.prove_combine(np.stack(parts)), wm[1:2]) == expect
     pk.close()
+
+
+def test_two_devices_two_keys_table_cache_and_current_device(emul, oracle):
+    """the table cache evicted idle tables of ANY device and left the current device switched.  In a child process
+    with two emulated devices (ZK_EMUL_DEVICES=2; the emulator tracks the calling thread's current device, the free memory it reports per
+    device and the allocations made on each): a context for key 2 on device 1 that is short of memory must not drop key 1's idle tables
+    on device 0, everything it allocates must be allocated with device 1 current, and freeing a key whose tables live on device 1 from a
+    thread whose current device is 0 must leave device 0 current"""
+    import subprocess, sys, os
+    from conftest import ROOT
+    child = r'''
+import ctypes as C, os, sys
+sys.path[:0] = [sys.argv[2], os.path.join(sys.argv[2], "tests"), os.path.join(sys.argv[2], "oracle")]
+import numpy as np
+import oracle_lib as O
+from ethsnarks_amd import prover as P, r1cs as R, fields as F
+P.load_library(sys.argv[1])
+L = P._lib
+L.zk_emul_alloc_count.restype = C.c_uint64
+allocs = lambda d: int(L.zk_emul_alloc_count(d))
+r, w = R.synthetic_chain(126, 1)
+wm = F.fr_to_mont(w)
+pk_o1, _ = O.keygen(r, seed=1); pk_o2, _ = O.keygen(r, seed=2)
+e1, e2 = O.prove(pk_o1, r, wm)[0], O.prove(pk_o2, r, wm)[0]
+k1 = P.ProvingKey.from_parts(**pk_o1.parts()); k2 = P.ProvingKey.from_parts(**pk_o2.parts())
+a0 = allocs(0)
+c = P.ProverContext(k1, r, device=0); assert P.prove(c, wm) == e1; c.close()        # key 1's tables stay cached on device 0 (idle)
+fresh = allocs(0) - a0
+a0 = allocs(0)
+c = P.ProverContext(k1, r, device=0); c.close()
+cached = allocs(0) - a0
+assert cached < fresh, (cached, fresh)                                             # the second context found the tables
+L.zk_emul_set_free_mem(1, C.c_size_t(1 << 20))                                      # device 1 is short of memory: the eviction loop runs
+a0, a1 = allocs(0), allocs(1)
+c2 = P.ProverContext(k2, r, device=1)
+assert allocs(0) == a0, "allocations of a device-1 context landed on device 0"
+assert allocs(1) > a1
+assert L.zk_emul_current_device() == 1
+assert P.prove(c2, wm) == e2
+a0 = allocs(0)
+c = P.ProverContext(k1, r, device=0); assert P.prove(c, wm) == e1; c.close()
+assert allocs(0) - a0 == cached, "key 1's idle tables on device 0 were evicted to make room on device 1"
+assert L.zk_emul_current_device() == 0
+c2.close(); k2.close()                                                              # frees tables that live on device 1 ...
+assert L.zk_emul_current_device() == 0, "zk_pk_free left the caller on another device"
+L.zk_emul_set_free_mem(0, C.c_size_t(1 << 20))                                      # ... and an eviction on device 0 does take device 0's idle set
+k3 = P.ProvingKey.from_parts(**pk_o2.parts())
+c3 = P.ProverContext(k3, r, device=0); assert P.prove(c3, wm) == e2; c3.close()
+a0 = allocs(0)
+c = P.ProverContext(k1, r, device=0); c.close()
+assert allocs(0) - a0 > cached, "key 1's idle tables should have been evicted on their own device"
+print("ok")
+'''
+    env = dict(os.environ, ZK_EMUL_DEVICES="2")
+    out = subprocess.run([sys.executable, "-c", child, emul, ROOT], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr

@@ -6,9 +6,14 @@
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 STEPS=${1:-40}
 cd $R
+LOG=${R}/gpurun_out/dev_marginal.err; mkdir -p $(dirname $LOG); : > $LOG
+# stderr is KEPT (round 3 sent it to /dev/null and lost the text of a device fault): one log for the whole sweep, and a run that prints no
+# JSON line ends the sweep with its stderr on the screen -- no further GPU step after a failed one
 run() {
-  ZK_EXP_SKIP="$2" ZK_LIB=$R/variants/marginal/libzkhip.so python bench.py --no-extras --no-cpu-baseline --witness resident --steps $STEPS --warmup 3 2>/dev/null \
-    | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('%-44s %8.3f ms/step  %7.2f proofs/s  launches/proof %.1f' % ('$1', d['ms_per_step'], d['value'], d['launches_per_proof']))"
+  echo "== $1 (ZK_EXP_SKIP=$2)" >> $LOG
+  ZK_EXP_SKIP="$2" ZK_LIB=$R/variants/marginal/libzkhip.so python bench.py --no-extras --no-cpu-baseline --witness resident --steps $STEPS --warmup 3 2>> $LOG \
+    | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('%-44s %8.3f ms/step  %7.2f proofs/s  launches/proof %.1f' % ('$1', d['ms_per_step'], d['value'], d['launches_per_proof']))" \
+    || { echo "run '$1' failed; stderr of the sweep so far:"; tail -n 40 $LOG; exit 1; }
 }
 S="k_sort_"; P="k_spmv"; N="k_ntt_pass"; F="k_msm_bucket_finalize"; H="k_msm_heavy"; G="k_msm_group_reduce"; T="k_msm_tree_sum"
 A1="k_msm_accumulate<C, 1>"; A2="k_msm_accumulate<C, 2>"
