@@ -659,16 +659,6 @@ struct Curve {
         r.ZZ = F::lmul(F::lmul(p.ZZ, q.ZZ), PP); r.ZZZ = F::lmul(F::lmul(p.ZZZ, q.ZZZ), PPP);
         return r;
     }
-    // k * p for a small non-negative integer k (bucket-offset weighting), MSB-first double-and-add
-    static ZK_HD XYZZ mul_small(const XYZZ &p, uint32_t k) {
-        XYZZ acc = infinity();
-        if (!k) return acc;
-        for (int i = 31 - __builtin_clz(k); i >= 0; i--) {
-            acc = dbl(acc);
-            if ((k >> i) & 1) acc = add(acc, p);
-        }
-        return acc;
-    }
     // ---- quad-cooperative forms.  Latency-bound kernels (the bucket reductions of small MSMs) run one logical thread
     // on FOUR adjacent lanes that hold the same operands; the independent field products of a formula are dealt to
     // the lanes round by round (lane ql takes product ql) and handed back with a DPP quad broadcast, so an addition
@@ -737,21 +727,12 @@ struct Curve {
     static ZK_HD XYZZ add_q(const XYZZ &p, const XYZZ &q, uint32_t) { return add(p, q); }
     static ZK_HD XYZZ madd_q(const XYZZ &p, const Affine &q, uint32_t) { return madd(p, q); }
 #endif
-    static ZK_HD XYZZ mul_small_q(const XYZZ &p, uint32_t k, uint32_t ql) {
-        XYZZ acc = infinity();
-        if (!k) return acc;
-        for (int i = 31 - __builtin_clz(k); i >= 0; i--) {
-            acc = dbl_q(acc, ql);
-            if ((k >> i) & 1) acc = add_q(acc, p, ql);
-        }
-        return acc;
-    }
     // Q lanes per logical thread: the plain forms for Q = 1, the quad forms for Q = 4
     template <int Q> static ZK_HD XYZZ addQ(const XYZZ &p, const XYZZ &q, uint32_t ql) { if constexpr (Q == 4) return add_q(p, q, ql); else return add(p, q); }
+    template <int Q> static ZK_HD XYZZ dblQ(const XYZZ &p, uint32_t ql) { if constexpr (Q == 4) return dbl_q(p, ql); else return dbl(p); }
     template <int Q> static ZK_HD XYZZ maddQ(const XYZZ &p, const Affine &q, uint32_t ql) { if constexpr (Q == 4) return madd_q(p, q, ql); else return madd(p, q); }
     // Q = 1: plain, 4: quad-cooperative, 2: one lane, product pairs (the machine-filling G1 accumulations)
     template <int Q> static ZK_HD XYZZ maddV(const XYZZ &p, const Affine &q, uint32_t ql) { if constexpr (Q == 2) return madd_pairs(p, q); else return maddQ<Q>(p, q, ql); }
-    template <int Q> static ZK_HD XYZZ mul_smallQ(const XYZZ &p, uint32_t k, uint32_t ql) { if constexpr (Q == 4) return mul_small_q(p, k, ql); else return mul_small(p, k); }
 
     // The formulas above run in the loose domain [0, 2p) of the field (no-op on the host).  to_affine normalises
     // its input and computes strictly, so affine outputs (tables, keys) are canonical; canon() normalises an XYZZ

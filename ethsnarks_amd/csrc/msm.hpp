@@ -20,8 +20,8 @@
 //   3 k_msm_accumulate  one thread per *chunk* of consecutive sorted entries (equal length for every thread, bucket
 //                       boundaries crossed inside the loop): XYZZ mixed additions   <- dominant kernel
 //   4 k_msm_bucket_finalize / k_msm_heavy   chunk pieces -> bucket sums
-//   5 k_msm_group_reduce   sum_b (b+1) * B_b over groups of buckets (running sums + small offset multiple)
-//   6 k_msm_tree_sum    LDS tree over the group partials -> the MSM result (one XYZZ point)
+//   5 k_msm_rowcol_sum  row and column sums of the bucket matrix (b = hi L + lo): LDS trees, no scalar multiplications
+//   6 k_msm_weighted_sum  L sum_hi hi Row_hi + sum_lo (lo + 1) Col_lo = sum_b (b + 1) B_b -> the MSM result (one XYZZ point per bucket set)
 // Kernels 3-6 are templated on the lanes per logical thread: <C, 1> for machine-filling sizes, <C, 4> (four lanes
 // share one point operation, Curve::add_q / dbl_q / madd_q in bn254.hpp) where a proof is a chain of dependent
 // additions rather than a throughput problem (MsmShape::quad / quad_acc).
@@ -39,13 +39,7 @@ constexpr uint32_t MSM_SEG_MIN = 32;      // entries per accumulation thread (lo
 constexpr uint32_t MSM_SEG_MIN_SMALL = 8; // ... and for MSMs of <= 2^23 entries, whose time is the serial chain per thread, not throughput
 constexpr uint32_t MSM_SEG_MAX = 64;      // ... upper bound: above it the entries are dealt in more than one round of the machine
 constexpr uint32_t MSM_HEAVY = 64;        // buckets with more chunk pieces than this are reduced by a workgroup
-constexpr uint32_t MSM_GROUP = 8;         // buckets per running-sum thread (ZK_MSM_GROUP overrides: tuning aid)
-constexpr uint32_t MSM_GROUP_SMALL = 4;   // ... for <= 2^15 buckets (latency-bound sizes; measured at 2^12 / 2^15 / 2^18, tools/dev_small_sweep.sh)
-inline uint32_t msm_group(uint32_t nb) {      // read once per MsmShape::set (context creation), never on the proving path
-    if (const char *e = getenv("ZK_MSM_GROUP")) { int v = atoi(e); if (v >= 1 && v <= 1024) return (uint32_t)v; }
-    return nb <= (1u << 15) ? MSM_GROUP_SMALL : MSM_GROUP;
-}
-constexpr uint32_t MSM_TREE = 256;        // fan-in (= workgroup size) of the final tree sum
+constexpr uint32_t MSM_TREE = 256;        // workgroup size of the row / column and weighted sums of the bucket reduction
 constexpr uint32_t MSM_HEAVY_GRID = 256;  // workgroups that walk the heavy-bucket list
 
 // shapes of the two-pass bucket sort (msm_impl.hpp); the CPU emulation of tests/emul runs these same shapes
@@ -112,11 +106,14 @@ struct MsmShape {
     uint32_t plog = 0;
     ZK_HD uint32_t planes() const { return 1u << plog; }
     ZK_HD uint32_t rows() const { return (W + planes() - 1) >> plog; }
-    uint32_t group = MSM_GROUP;     // buckets per running-sum thread
+    // the bucket matrix of the reduction: bucket b = hi * 2^lo_bits + lo (k_msm_rowcol_sum)
+    ZK_HD uint32_t lo_bits() const { return c / 2; }
+    ZK_HD uint32_t hi_bits() const { return (c - 1) - c / 2; }
     ChunkRule chunk;
     uint32_t quad = 1;      // lanes per logical thread in the bucket-reduction kernels: 1, or 4 (Curve::*_q) for latency-bound sizes
     uint32_t quad_acc = 1;  // ... and in the accumulation kernel (only while 4 lanes per chunk still fit the machine at once)
     bool acc_pairs = false; // G1 accumulation with dual-issue product pairs at 3 waves/SIMD (k_msm_accumulate<C, 2>): machine-filling sizes only
+    uint32_t rowcol_seg = 16; // threads that share one row / column sum in k_msm_rowcol_sum when the tail is throughput work (one lane per thread)
     // largest window with >= T entries per bucket on average (n * W entries over 2^(c-1) buckets).  T = 32 for one proof at a time:
     // the bucket reduction is latency there and a larger window shortens the accumulation chains.  A batch pays the reduction of
     // every proof's buckets in throughput once its entries fill the machine, and wants fuller buckets: T grows with the entries of
@@ -147,7 +144,6 @@ struct MsmShape {
         if (c < 2) c = 2;
         if (c > 20) c = 20;
         W = 254 / c + 1; nb = 1u << (c - 1);
-        group = msm_group(nb);
         // measured (tools/dev_small_sweep.sh, domains 2^13 .. 2^19): quad reductions win up to 2^17 constraints with one or
         // three proofs in flight (and still for a single proof beyond); quad accumulation only while the GPU is mostly idle
         const uint64_t all = max_entries() * (batch ? batch : 1);
@@ -159,6 +155,7 @@ struct MsmShape {
         // (synchronous proofs, tools/dev_sync_latency.py, plain -> pairs: 2^17 2.38 -> 2.59 ms, 2^18 3.56 -> 3.72, 2^20 10.8 -> 10.4)
         acc_pairs = all >= (3ull << 21);
         if (const char *e = getenv("ZK_ACC_PAIRS")) acc_pairs = atoi(e) != 0;
+        if (const char *e = getenv("ZK_ROWCOL_SEG")) { int v = atoi(e); if (v >= 1 && v <= 256 && !(v & (v - 1))) rowcol_seg = (uint32_t)v; }
         chunk.seg_min = all <= (1ull << 23) ? MSM_SEG_MIN_SMALL : MSM_SEG_MIN;
         chunk.seg_max = MSM_SEG_MAX;
         if (const char *e = getenv("ZK_SEG_MIN")) { int v = atoi(e); if (v >= 4) chunk.seg_min = (uint32_t)v; }    // tuning aids
@@ -229,8 +226,7 @@ struct MsmWork {
     int enqueue_accumulate(const SortView &v, hipStream_t st);
     int enqueue_tail(hipStream_t st_tail, uint32_t tail_lanes = 0, MsmWork *also = nullptr);
     bool tail_pending = false;                  // an accumulation whose chunk pieces no tail has consumed yet
-    template <int Q> int launch_reduce(uint32_t K, uint32_t groups, hipStream_t st, const MsmWork *also);
-    uint32_t tree_levels(uint32_t groups, uint32_t lanes) const;
+    template <int Q> int launch_reduce(hipStream_t st, const MsmWork *also);
     const uint32_t *cur_off = nullptr;          // bucket offsets of the sort driving the current reduction
     uint32_t sort_batch = 1;                    // batch of the last enqueue_sort
     uint32_t sort_kbits = 0;                    // sort-only objects (the shared witness sort): entries carry (window << kbits) | scalar -- set by use_shift_payload()

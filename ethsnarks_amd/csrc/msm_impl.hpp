@@ -377,39 +377,100 @@ k_msm_heavy(const typename C::XYZZ *__restrict__ piece, const uint32_t *__restri
     }
 }
 
-// thread / quad per group of K consecutive buckets:  sum_j (g*K + j + 1) * B_{g*K+j}
-template <class C, int Q>
-__global__ void __launch_bounds__(64, C::WAVES_PER_SIMD / 2)
-k_msm_group_reduce(const typename C::XYZZ *__restrict__ bucket, uint32_t nb, uint32_t K, uint32_t groups_per_proof,
-                   typename C::XYZZ *__restrict__ partial) {
-    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x, g = gt / Q, ql = gt % Q;
-    if (g >= nb / K) return;                                   // nb: buckets of all proofs of the batch
-    const typename C::XYZZ *B = bucket + (size_t)g * K;
-    typename C::XYZZ run = C::infinity(), acc = C::infinity();
-    for (uint32_t j = K; j-- > 0;) { run = C::template addQ<Q>(run, B[j], ql); acc = C::template addQ<Q>(acc, run, ql); }
-    const uint32_t gl = g % groups_per_proof;                  // the weights restart with every proof's bucket set
-    if (gl) acc = C::template addQ<Q>(acc, C::template mul_smallQ<Q>(run, gl * K, ql), ql);
-    if (ql == 0) partial[g] = acc;
-}
-
-// out[blockIdx] = sum of in[blockIdx*T .. +T) (bounded by count), T = msm_tree_fan(Q) logical threads of Q lanes:
-// LDS tree, upper half parks.  blockIdx.y = proof of a batch: its `count` inputs and gridDim.x outputs lie side by side.
+// ---- bucket sums -> sum_b (b + 1) B_b WITHOUT scalar multiplications (round 4).  Write bucket b = hi * L + lo (L = 2^lo_bits columns, H = 2^hi_bits rows):
+//     sum_b (b + 1) B_b  =  L * sum_hi hi * Row_hi  +  sum_lo (lo + 1) * Col_lo,      Row_hi = sum_lo B_{hi,lo},  Col_lo = sum_hi B_{hi,lo}
+// k_msm_rowcol_sum forms the H + L sums: 2 additions per bucket, like the running sums of the per-group reduction of rounds 1-3 (a thread per 8 buckets:
+// run += B_j, acc += run, then acc += mul_small(run, 8 g)), but without that scalar multiplication per group -- 60 % of its dependent chain and 196 k of
+// the 640 k point operations of a 2^16-bucket tail -- and in kernels that fit beside a resident accumulation wave (the G2 group reduction held 432
+// registers per lane).  Same-box A/B at 2^20, three proofs in flight: +2.7 % on one box, +7.9 % on another; one synchronous proof 2^16 1.60 -> 1.38 ms,
+// 2^18 3.38 -> 3.20, 2^20 9.97 -> 9.82; unbatched Merkle-29 785 -> 1 042 proofs/s (profiles/r04_rowcol_tail_ab.txt).
+// k_msm_weighted_sum: ONE workgroup per bucket set turns the H row sums and the L column sums into the result: each half of the workgroup forms
+// sum_i i X_i of its vector (a thread's own run serially, the thread totals by a suffix scan: sum_t t S_t = sum_{k >= 1} suffix_k, one LDS tree), the
+// row half scales by L (lo_bits doublings), the column half adds sum_i X_i.
+// `seg` logical threads (a power of two, <= T) share one row / column: each sums n / seg of its elements serially, an LDS tree of log2(seg) levels
+// follows; a workgroup of T logical threads takes T / seg rows (or columns).  seg = 16 keeps 84 % of the lane-cycles busy (a 256-wide tree over 256
+// elements: 11 %) -- the throughput shape; seg = T is the shortest chain -- the shape of one synchronous proof.  Rows first, then columns:
+// workgroups [0, row_groups) take rows, the rest columns.
 template <class C, int Q>
 __global__ void __launch_bounds__(MSM_TREE)
-k_msm_tree_sum(const typename C::XYZZ *__restrict__ in, uint32_t count, typename C::XYZZ *__restrict__ out) {
+k_msm_rowcol_sum(const typename C::XYZZ *__restrict__ bucket, uint32_t lo_bits, uint32_t hi_bits, uint32_t seg_row, uint32_t seg_col, uint32_t row_groups,
+                 typename C::XYZZ *__restrict__ rc) {
     constexpr uint32_t T = MSM_TREE / Q;
     __shared__ typename C::XYZZ sh[T / 2];
-    in += (size_t)blockIdx.y * count; out += (size_t)blockIdx.y * gridDim.x;
+    const uint32_t L = 1u << lo_bits, H = 1u << hi_bits;
+    bucket += ((size_t)blockIdx.y << (lo_bits + hi_bits)); rc += (size_t)blockIdx.y * (H + L);      // blockIdx.y: the bucket set
     const uint32_t lt = threadIdx.x / Q, ql = threadIdx.x % Q;
-    const uint32_t i = blockIdx.x * T + lt;
-    typename C::XYZZ acc = i < count ? in[i] : C::infinity();
-    for (uint32_t half = T / 2; half > 0; half >>= 1) {
-        if (lt >= half && lt < 2 * half && ql == 0) sh[lt - half] = acc;
+    const bool row = blockIdx.x < row_groups;
+    const uint32_t seg = row ? seg_row : seg_col, per = T / seg;                                   // threads per line, lines per workgroup
+    const uint32_t line = (row ? blockIdx.x : blockIdx.x - row_groups) * per + lt / seg, k = lt % seg;
+    const uint32_t n = row ? L : H, lines = row ? H : L;
+    const bool live = line < lines;
+    const uint32_t first = row ? line << lo_bits : line, step = row ? 1u : L;
+    typename C::XYZZ acc = C::infinity();
+    if (live) for (uint32_t i = k; i < n; i += seg) acc = C::template addQ<Q>(acc, bucket[first + (size_t)i * step], ql);
+    for (uint32_t half = seg / 2; half > 0; half >>= 1) {                                           // tree inside every segment of `seg` threads
+        if (k >= half && k < 2 * half && ql == 0) sh[(lt / seg) * (seg / 2) + (k - half)] = acc;
         __syncthreads();
-        if (lt < half) acc = C::template addQ<Q>(acc, sh[lt], ql);
+        if (k < half) acc = C::template addQ<Q>(acc, sh[(lt / seg) * (seg / 2) + k], ql);
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[blockIdx.x] = acc;
+    if (live && k == 0 && ql == 0) rc[row ? line : H + line] = acc;
+}
+
+template <class C, int Q>
+__global__ void __launch_bounds__(MSM_TREE)
+k_msm_weighted_sum(const typename C::XYZZ *__restrict__ rc, uint32_t lo_bits, uint32_t hi_bits, typename C::XYZZ *__restrict__ out) {
+    constexpr uint32_t TH = MSM_TREE / Q / 2;                 // logical threads per half: rows | columns
+    __shared__ typename C::XYZZ sh[2 * TH];                   // (G2, one lane per thread: 256 x 256 B = 64 KiB)
+    const uint32_t L = 1u << lo_bits, H = 1u << hi_bits;
+    rc += (size_t)blockIdx.x * (H + L);                       // blockIdx.x: the bucket set
+    const uint32_t lt = threadIdx.x / Q, ql = threadIdx.x % Q, half = lt / TH, t = lt % TH;
+    const uint32_t n = half ? L : H;
+    const typename C::XYZZ *X = rc + (half ? H : 0);
+    typename C::XYZZ *mine = sh + half * TH;
+    const uint32_t W = n < TH ? n : TH;                        // threads of this half that hold elements (powers of two); W differs between the halves
+    const uint32_t Wmax = (L > H ? L : H) < TH ? (L > H ? L : H) : TH;       // ... the loop bounds are those of the wider half (uniform barriers)
+    const uint32_t E = n / W, i0 = t * E;                     // elements per thread
+    // own run: run = sum_e X_{i0+e}, acc = sum_e e X_{i0+e}
+    typename C::XYZZ run = C::infinity(), acc = C::infinity();
+    if (t < W) for (uint32_t e = E; e-- > 0;) {
+        run = C::template addQ<Q>(run, X[i0 + e], ql);
+        if (e) acc = C::template addQ<Q>(acc, run, ql);
+    }
+    // suffix scan of the thread totals: suf_t = sum_{t' >= t} run_t'
+    typename C::XYZZ suf = run;
+    if (ql == 0) mine[t] = suf;
+    __syncthreads();
+    for (uint32_t d = 1; d < Wmax; d <<= 1) {
+        typename C::XYZZ other = C::infinity();
+        if (t + d < W) other = mine[t + d];
+        __syncthreads();
+        if (t < W && d < W) { suf = C::template addQ<Q>(suf, other, ql); if (ql == 0) mine[t] = suf; }
+        __syncthreads();
+    }
+    const typename C::XYZZ total = mine[0];                   // sum_i X_i of this half
+    __syncthreads();
+    // sum_i i X_i = sum_t (acc_t + E t run_t) = sum_t acc_t + E sum_{k >= 1} suf_k
+    typename C::XYZZ v = (t && t < W) ? suf : C::infinity();
+    for (uint32_t e = E; e > 1; e >>= 1) v = C::template dblQ<Q>(v, ql);
+    v = C::template addQ<Q>(v, acc, ql);
+    for (uint32_t h = Wmax / 2; h > 0; h >>= 1) {
+        if (t >= h && t < 2 * h && ql == 0) mine[t - h] = v;
+        __syncthreads();
+        if (t < h) v = C::template addQ<Q>(v, mine[t], ql);
+        __syncthreads();
+    }
+    // rows: L * sum_hi hi Row_hi;   columns: sum_lo lo Col_lo + sum_lo Col_lo
+    if (t == 0) {
+        if (half == 0) for (uint32_t b = 0; b < lo_bits; b++) v = C::template dblQ<Q>(v, ql);
+        else v = C::template addQ<Q>(v, total, ql);
+        if (ql == 0) mine[0] = v;
+    }
+    __syncthreads();
+    if (lt == 0) {
+        v = C::template addQ<Q>(v, sh[TH], ql);
+        if (ql == 0) out[blockIdx.x] = v;
+    }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -422,7 +483,6 @@ int MsmWork<C>::alloc(uint32_t n, uint32_t c, typename C::Affine *shared_table, 
     if ((uint64_t)sh.n * sh.rows() >= (1ull << 31)) return fail_msg(ZK_ERR_ARG, "MSM too large: n * table rows must stay below 2^31 (entry payload = table index | sign)");
     if (sh.max_entries() * B >= (1ull << 32) - 64) return fail_msg(ZK_ERR_ARG, "MSM too large: proofs * n * windows must stay below 2^32 (32-bit entry offsets)");
     if ((uint64_t)sh.nb * BS > (uint64_t)SORT_MAX_CB * SORT_MAX_FB) return fail_msg(ZK_ERR_ARG, "batch too large: proofs * planes * buckets exceeds the sort's 2^20 buckets");
-    const uint32_t G0 = sh.group, K = sh.nb < G0 ? sh.nb : G0, groups = sh.nb / K;
     if (sort_only) { owns_table = false; table_n = n; }
     else if (shared_table) { table = shared_table; owns_table = false; table_n = n; }
     else ZK_HIP(hipMalloc(&table, sizeof(typename C::Affine) * (size_t)(n ? n : 1) * sh.rows()));
@@ -441,8 +501,9 @@ int MsmWork<C>::alloc(uint32_t n, uint32_t c, typename C::Affine *shared_table, 
     ZK_HIP(hipMalloc(&heavy_count, sizeof(uint32_t)));
     ZK_HIP(hipMalloc(&pieces, sizeof(typename C::XYZZ) * n_pieces));
     ZK_HIP(hipMalloc(&bucket, sizeof(typename C::XYZZ) * sh.nb * BS));
-    ZK_HIP(hipMalloc(&partial_a, sizeof(typename C::XYZZ) * ((size_t)groups * BS + 1)));
-    ZK_HIP(hipMalloc(&partial_b, sizeof(typename C::XYZZ) * ((size_t)zk_div_up(groups, MSM_TREE / 4) * BS + 1)));   // sized for 4 lanes per thread (the smaller fan-in), whichever a call uses
+    const uint32_t rowcol = (1u << sh.lo_bits()) + (1u << sh.hi_bits());          // row + column sums per bucket set (k_msm_rowcol_sum)
+    ZK_HIP(hipMalloc(&partial_a, sizeof(typename C::XYZZ) * ((size_t)rowcol * BS + 1)));
+    ZK_HIP(hipMalloc(&partial_b, sizeof(typename C::XYZZ) * (BS + 1)));                // one result per bucket set (k_msm_weighted_sum)
     ZK_HIP(hipHostMalloc(&host_result, sizeof(typename C::XYZZ) * BS, hipHostMallocDefault));
     ZK_HIP(hipEventCreate(&ev_acc0)); ZK_HIP(hipEventCreate(&ev_acc1));
     return ZK_OK;
@@ -489,19 +550,11 @@ int MsmWork<C>::enqueue_sort(const fe *scalars, const uint32_t *gather, uint32_t
     return ZK_OK;
 }
 
-// number of tree-sum launches that take `groups` partials to one point (ping-pong partial_a -> partial_b -> ...)
-template <class C>
-uint32_t MsmWork<C>::tree_levels(uint32_t groups, uint32_t lanes) const {
-    uint32_t levels = 0, count = groups;
-    do { count = zk_div_up(count, MSM_TREE / lanes); levels++; } while (count > 1);
-    return levels;
-}
-
 // bucket reduction with Q lanes per logical thread
 template <class C>
 template <int Q>
-int MsmWork<C>::launch_reduce(uint32_t K, uint32_t groups, hipStream_t st, const MsmWork<C> *also) {      // groups: per proof
-    const uint32_t nb = sh.nb * cur_batch, all_groups = groups * cur_batch;
+int MsmWork<C>::launch_reduce(hipStream_t st, const MsmWork<C> *also) {
+    const uint32_t nb = sh.nb * cur_batch;                    // buckets of all bucket sets (proofs x planes)
     const typename C::XYZZ *piece2 = also ? also->pieces : nullptr;
     const uint32_t *off2 = also ? also->cur_off : nullptr;
     const ChunkRule rule2 = also ? also->sh.chunk : sh.chunk;
@@ -509,15 +562,18 @@ int MsmWork<C>::launch_reduce(uint32_t K, uint32_t groups, hipStream_t st, const
               piece2, off2, rule2, bucket, heavy_list, heavy_count);
     ZK_LAUNCH_SYNC((k_msm_heavy<C, Q>), MSM_HEAVY_GRID, 128 * Q, st, (const typename C::XYZZ *)pieces, (const uint32_t *)cur_off, nb, sh.chunk,
                    piece2, off2, rule2, (const uint32_t *)heavy_list, (const uint32_t *)heavy_count, bucket);
-    ZK_LAUNCH((k_msm_group_reduce<C, Q>), zk_div_up((uint64_t)all_groups * Q, 64), 64, st, (const typename C::XYZZ *)bucket, nb, K, groups, partial_a);
-    typename C::XYZZ *cur = partial_a, *nxt = partial_b;
-    uint32_t count = groups;
-    do {
-        uint32_t outc = zk_div_up(count, MSM_TREE / Q);
-        ZK_LAUNCH_SYNC((k_msm_tree_sum<C, Q>), dim3(outc, cur_batch), MSM_TREE, st, (const typename C::XYZZ *)cur, count, nxt);
-        typename C::XYZZ *t = cur; cur = nxt; nxt = t;
-        count = outc;
-    } while (count > 1);
+    // row / column sums (partial_a), then one weighted sum per bucket set: the results land in partial_b
+    const uint32_t lo_bits = sh.lo_bits(), hi_bits = sh.hi_bits();            // nb = 2^(c-1) = H L
+    const uint32_t L = 1u << lo_bits, H = 1u << hi_bits, T = MSM_TREE / Q;
+    // threads per row / column: the whole workgroup for latency-sized work (Q = 4: a synchronous proof or a small one), 16 where the tails share
+    // the machine with the accumulations of other proofs (84 % of the lane-cycles useful instead of 11 %; ZK_ROWCOL_SEG sweep at 2^20, three proofs
+    // in flight: 4: 107.1, 8: 109.4, 16: 111.5 / 110.8, 32: 109.1, 256: 106.1 proofs/s)
+    const uint32_t want = Q == 4 ? T : sh.rowcol_seg;
+    const uint32_t seg_row = want < L ? want : L, seg_col = want < H ? want : H;
+    const uint32_t row_groups = zk_div_up(H, T / seg_row), col_groups = zk_div_up(L, T / seg_col);
+    ZK_LAUNCH_SYNC((k_msm_rowcol_sum<C, Q>), dim3(row_groups + col_groups, cur_batch), MSM_TREE, st, (const typename C::XYZZ *)bucket, lo_bits, hi_bits,
+                   seg_row, seg_col, row_groups, partial_a);
+    ZK_LAUNCH_SYNC((k_msm_weighted_sum<C, Q>), cur_batch, MSM_TREE, st, (const typename C::XYZZ *)partial_a, lo_bits, hi_bits, partial_b);
     return ZK_OK;
 }
 
@@ -558,7 +614,6 @@ int MsmWork<C>::enqueue_tail(hipStream_t st_tail, uint32_t tail_lanes, MsmWork<C
     if (!tail_pending) return fail_msg(ZK_ERR_ARG, "MSM tail: no accumulation is pending");
     if (also && (!also->tail_pending || also->sh.nb != sh.nb || also->sh.plog != sh.plog || also->cur_batch != cur_batch)) return fail_msg(ZK_ERR_ARG, "MSM tail: the accumulation to fold in has other buckets or another batch");
     tail_pending = false;
-    const uint32_t G0 = sh.group, K = sh.nb < G0 ? sh.nb : G0, groups = sh.nb / K;   // running-sum groups per proof
     hipStream_t st = st_tail;
     ZK_HIP(hipStreamWaitEvent(st, ev_acc1, 0));
     if (also) {
@@ -568,9 +623,9 @@ int MsmWork<C>::enqueue_tail(hipStream_t st_tail, uint32_t tail_lanes, MsmWork<C
     }
     ZK_HIP(hipMemsetAsync(heavy_count, 0, sizeof(uint32_t), st));
     const uint32_t lanes = tail_lanes == 4 || tail_lanes == 1 ? tail_lanes : sh.quad;
-    const int rc = lanes == 4 ? launch_reduce<4>(K, groups, st, also) : launch_reduce<1>(K, groups, st, also);
+    const int rc = lanes == 4 ? launch_reduce<4>(st, also) : launch_reduce<1>(st, also);
     if (rc != ZK_OK) return rc;
-    typename C::XYZZ *cur = (tree_levels(groups, lanes) & 1) ? partial_b : partial_a;
+    typename C::XYZZ *cur = partial_b;
     ZK_HIP(hipGetLastError());
     ZK_HIP(hipMemcpyAsync(host_result, cur, sizeof(typename C::XYZZ) * cur_batch, hipMemcpyDeviceToHost, st));
     if (dev_result && sh.plog == 0) {                           // (frugal tables: the planes are folded on the host, which then writes the device copy: zkhip.cpp)

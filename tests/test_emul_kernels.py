@@ -505,3 +505,18 @@ print("ok")
     env = dict(os.environ, ZK_EMUL_DEVICES="2")
     out = subprocess.run([sys.executable, "-c", child, emul, ROOT], capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("seg", ["1", "4", "256"])
+def test_msm_row_column_reduction_shapes(zk, oracle, monkeypatch, seg):
+    """the bucket reduction by row / column sums (k_msm_rowcol_sum, k_msm_weighted_sum): segment widths (threads per row), window sizes with
+    square (c - 1 even) and 2 : 1 (c - 1 odd) bucket matrices, one and four lanes per thread, against the oracle"""
+    monkeypatch.setenv("ZK_ROWCOL_SEG", seg)
+    n = 220
+    s = F.fr_to_mont([1] * 60 + rand_scalars(n - 60, 12, zeros_every=9))
+    for g2 in (False, True):
+        bases = oracle.batch_mul(F.fr_to_mont(rand_scalars(n, 23)), g2=g2)
+        expect = oracle.msm(bases, s, g2=g2)
+        for c, quad in ((2, "0"), (3, "1"), (8, "0"), (9, "1"), (9, "0")):
+            monkeypatch.setenv("ZK_MSM_QUAD", quad)
+            assert np.array_equal(zk.msm(bases, s, g2=g2, c=c), expect), (g2, c, quad)

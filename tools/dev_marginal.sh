@@ -15,7 +15,7 @@ run() {
     | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('%-44s %8.3f ms/step  %7.2f proofs/s  launches/proof %.1f' % ('$1', d['ms_per_step'], d['value'], d['launches_per_proof']))" \
     || { echo "run '$1' failed; stderr of the sweep so far:"; tail -n 40 $LOG; exit 1; }
 }
-S="k_sort_"; P="k_spmv"; N="k_ntt_pass"; F="k_msm_bucket_finalize"; H="k_msm_heavy"; G="k_msm_group_reduce"; T="k_msm_tree_sum"
+S="k_sort_"; P="k_spmv"; N="k_ntt_pass"; F="k_msm_bucket_finalize"; H="k_msm_heavy"; G="k_msm_rowcol_sum"; T="k_msm_weighted_sum"
 A1="k_msm_accumulate<C, 1>"; A2="k_msm_accumulate<C, 2>"
 run "everything" ""
 run "no sorts" "$S"
@@ -26,8 +26,8 @@ run "accumulations + sorts" "$P;$N;$F;$H;$G;$T"
 run "accumulations + rows + transforms" "$S;$F;$H;$G;$T"
 run "accumulations + finalize" "$S;$P;$N;$H;$G;$T"
 run "accumulations + heavy" "$S;$P;$N;$F;$G;$T"
-run "accumulations + group_reduce" "$S;$P;$N;$F;$H;$T"
-run "accumulations + tree_sum" "$S;$P;$N;$F;$H;$G"
+run "accumulations + rowcol_sum" "$S;$P;$N;$F;$H;$T"
+run "accumulations + weighted_sum" "$S;$P;$N;$F;$H;$G"
 run "accumulations + all tails" "$S;$P;$N"
 run "G2 accumulation only" "$A2;$S;$P;$N;$F;$H;$G;$T"
 run "G2 accumulation + sorts" "$A2;$P;$N;$F;$H;$G;$T"
