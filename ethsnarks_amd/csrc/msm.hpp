@@ -37,7 +37,9 @@ namespace zk {
 
 constexpr uint32_t MSM_SEG_MIN = 32;      // entries per accumulation thread (lower bound) when the entries fill the machine
 constexpr uint32_t MSM_SEG_MIN_SMALL = 8; // ... and for MSMs of <= 2^23 entries, whose time is the serial chain per thread, not throughput
-constexpr uint32_t MSM_SEG_MAX = 64;      // ... upper bound: above it the entries are dealt in more than one round of the machine
+constexpr uint32_t MSM_SEG_MAX = 48;      // ... upper bound: above it the entries are dealt in more than one round of the machine (round 4, with the row / column
+                                          // reduction: ZK_SEG_MAX 32 / 40 / 48 / 56 / 64 = 114.5 / 114.6 / 114.6 / 114.1 / 113.6 proofs/s at 2^20, two runs each --
+                                          // the G2 accumulation deals its 15.7 M entries in three rounds of 40 instead of two of 60)
 constexpr uint32_t MSM_HEAVY = 64;        // buckets with more chunk pieces than this are reduced by a workgroup
 constexpr uint32_t MSM_TREE = 256;        // workgroup size of the row / column and weighted sums of the bucket reduction
 constexpr uint32_t MSM_HEAVY_GRID = 256;  // workgroups that walk the heavy-bucket list
