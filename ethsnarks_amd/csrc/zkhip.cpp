@@ -161,9 +161,9 @@ static_assert(sizeof(zk_partials) == 640, "zk_partials layout");
 // ================================================================ library / device
 extern "C" const char *zk_version(void) {
 #ifdef ZK_EMUL
-    return "zkhip 0.3.0 (CPU EMULATION BUILD - tests only)";
+    return "zkhip 0.4.0 (CPU EMULATION BUILD - tests only)";
 #else
-    return "zkhip 0.3.0 (gfx950)";
+    return "zkhip 0.4.0 (gfx950)";
 #endif
 }
 extern "C" uint32_t zk_abi_version(void) { return ZK_ABI_VERSION; }

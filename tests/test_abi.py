@@ -195,3 +195,50 @@ def test_every_extern_c_definition_ends_in_the_exception_barrier():
                 depth += {"(": 1, ")": -1}.get(src[j], 0); j += 1
             rest = src[j:j + 8].lstrip()
             assert rest.startswith("try") or rest.startswith(";"), (name, m.group(2))
+
+
+@pytest.mark.skipif(not os.path.exists(LIB), reason="libzkhip.so not built (run __graft_entry__.build())")
+def test_raw_reader_survives_mutated_key_files(tmp_path):
+    """400 mutations of a well-formed nozk .raw key (flipped bytes in the headers and counts, truncations, inserted digits, swapped
+    newlines): zk_pk_load_raw answers ZK_OK or ZK_ERR_FORMAT every time -- no crash, no other code -- and what it accepts has the
+    declared sizes.  Host-only entry point: runs without a GPU."""
+    import random
+    L = C.CDLL(LIB)
+    P1 = b"0" + bytes(range(1, 65)); P2 = b"0" + bytes(range(1, 129))
+    def sparse(domain, idx, pts): return b"%d\n%d\n" % (domain, len(idx)) + b"".join(b"%d\n" % i for i in idx) + b"%d\n" % len(idx) + b"".join(pts)
+    good = P1 + P1 + P2 + P1 + P2 + sparse(9, [0, 2, 5, 8], [P1] * 4) + sparse(9, [1, 2, 7], [P2] * 3) + b"7\n" + P1 * 7 + b"5\n" + P1 * 5
+    path = str(tmp_path / "k.raw")
+    def load(blob):
+        open(path, "wb").write(blob)
+        out = C.c_void_p()
+        rc = L.zk_pk_load_raw(path.encode(), 0, C.byref(out))
+        sizes = None
+        if rc == 0:
+            s = (C.c_uint32 * 6)()
+            assert L.zk_pk_sizes(out, s) == 0
+            sizes = list(s)
+            L.zk_pk_free(out)
+        return rc, sizes
+    assert load(good) == (0, [9, 4, 9, 3, 7, 5])
+    rng = random.Random(5)
+    text_at = [i for i, b in enumerate(good) if b in b"0123456789\n"]        # bytes that are (or look like) header text
+    seen = {0: 0, 3: 0}
+    for it in range(400):
+        b = bytearray(good)
+        kind = it % 5
+        if kind == 0:                                   # flip a header-looking byte
+            i = rng.choice(text_at); b[i] = rng.choice(b"0123456789\n x\xff")
+        elif kind == 1:                                 # truncate anywhere
+            del b[rng.randrange(1, len(b)):]
+        elif kind == 2:                                 # make a count huge
+            i = rng.choice(text_at); b[i:i] = b"9" * rng.randrange(1, 14)
+        elif kind == 3:                                 # flip any byte at all
+            b[rng.randrange(len(b))] ^= 1 << rng.randrange(8)
+        else:                                           # drop a byte
+            del b[rng.randrange(len(b))]
+        rc, sizes = load(bytes(b))
+        assert rc in (0, 3), (it, kind, rc)
+        seen[rc] += 1
+        if rc == 0:
+            assert sizes[1] <= sizes[0] and sizes[3] <= sizes[2]
+    assert seen[3] > 100 and seen[0] > 10                  # (flips inside coordinate bytes leave a well-formed file)
