@@ -5,4 +5,4 @@ src/r1cs_gg_ppzksnark_zok/r1cs_gg_ppzksnark_zok.tcc:451-550.  Compute is hand-wr
 (ethsnarks_amd/csrc, built into libzkhip.so, C ABI in include/zkhip.h); this Python package is the
 thin host-side binding used by tests/ and bench.py.
 """
-__version__ = "0.3.0"
+__version__ = "0.4.0"
