@@ -158,6 +158,27 @@ def test_prove_random_circuits_vs_oracle(hip, oracle):
         assert hip.prove(one, wm) == expect and hip.prove(one, wm) == expect
 
 
+@pytest.mark.parametrize("nC,small,batch", [(20000, True, 1), (50000, False, 1), (9000, True, 3)])
+def test_prove_mid_size_structured_witnesses_vs_oracle(hip, oracle, nC, small, batch):
+    """mid-size random circuits (domains 2^14 ... 2^16: other window sizes and bucket matrices than the chain sizes), with 0 / 1 / 2 / 3-valued
+    witnesses (one bucket holds most entries: the heavy-bucket path inside the merged H + L tail and the row / column reduction), pipelined
+    (two tails merged) and synchronous (small proofs keep the L tail), and as a batch of different witnesses of one circuit"""
+    r, w = R.random_r1cs(nC, 2, seed=nC, small_values=small, max_terms=3)
+    wm = F.fr_to_mont(w)
+    pk_o, _ = oracle.keygen(r, seed=nC + 1)
+    pk = hip.ProvingKey.from_parts(**pk_o.parts())
+    expect, _ = oracle.prove(pk_o, r, wm)
+    ctx = hip.ProverContext(pk, r, max_batch=batch)
+    assert hip.prove(ctx, wm) == expect                              # synchronous entry point
+    ctx.submit(wm)                                                   # queued entry point (merged tail)
+    part, _ = ctx.collect()
+    assert hip.proof_to_json(ctx.prove_combine(part), wm[1:3]) == expect
+    if batch > 1:
+        ws = [wm] + [F.fr_to_mont(R.random_r1cs(nC, 2, seed=nC, small_values=small, max_terms=3, witness_seed=100 + i)[1]) for i in range(batch - 1)]
+        assert hip.prove_batch(ctx, np.stack(ws)) == [oracle.prove(pk_o, r, x)[0] for x in ws]
+    ctx.close(); pk.close()
+
+
 def test_prove_shape_sweep_vs_oracle(hip, oracle):
     """domain-size boundaries (nC + nIn + 1 on either side of a power of two), no public inputs, one constraint, dense and
     sparse rows, unreferenced variables, 0/1-heavy witnesses: every proof byte-equal to the oracle's"""
