@@ -720,6 +720,7 @@ struct zk_ctx {
     char env_h_borrow = 0;                     // ZK_H_BORROW=a / l / b picks the borrowed stream (0: by entry point)
     char env_hl_tail = 0;                      // ZK_HL_TAIL=l / a: the merged H + L bucket reduction on the L- / A-tail stream instead of the H pipeline's (0)
     int env_b_tail_lanes = 0;                  // ZK_B_TAIL_LANES=1 / 4: lanes per point operation of the B-query's (G2) bucket reduction (0: by size / entry point)
+    bool env_tails_on_acc = false;             // ZK_TAILS_ON_ACC=1: every bucket reduction on the accumulation stream, behind its accumulation (experiment)
     hipEvent_t ev_sort = nullptr;              // a finished bucket sort on s_main releases its accumulation on s_acc
     hipEvent_t ev_start = nullptr, ev_w = nullptr, ev_h = nullptr, ev_a0 = nullptr, ev_a1 = nullptr, ev_b0 = nullptr, ev_b1 = nullptr,
                ev_l0 = nullptr, ev_l1 = nullptr, ev_h1 = nullptr, ev_h0 = nullptr;
@@ -898,6 +899,7 @@ static int ctx_build(zk_ctx *c, const zk_pk *pk, const zk_csr *A, const zk_csr *
     if (const char *e = getenv("ZK_H_BORROW")) c->env_h_borrow = e[0];
     if (const char *e = getenv("ZK_HL_TAIL")) c->env_hl_tail = e[0];
     if (const char *e = getenv("ZK_B_TAIL_LANES")) c->env_b_tail_lanes = atoi(e);
+    c->env_tails_on_acc = getenv("ZK_TAILS_ON_ACC") != nullptr;
     const char *serial = getenv("ZK_SERIAL");
     c->serial = (serial && serial[0] == '1') || c->cfg.schedule == ZK_SCHED_ONE_STREAM;
     const char *split = getenv("ZK_SPLIT_STREAMS");
@@ -1112,11 +1114,11 @@ static int prove_enqueue(zk_ctx *c, const uint64_t *witness, int canonical, int 
     if (!t->share_B) { ZK_TRY(c->mB.enqueue_sort(c->d_w, c->dB_idx, c->rB.n(), 0, m, k, ws)); ZK_TRY(release()); }
     if (split_h) ZK_TRY(h_pipeline());
     ZK_HIP(hipEventRecord(c->ev_b0, q));
-    ZK_TRY(c->mB.enqueue_reduce(t->share_B ? c->mW.view_for(t->offB, t->posB) : c->mB.view(), q, c->s_b, c->env_b_tail_lanes ? (uint32_t)c->env_b_tail_lanes : tail_lanes));    // tcc:499-506
+    ZK_TRY(c->mB.enqueue_reduce(t->share_B ? c->mW.view_for(t->offB, t->posB) : c->mB.view(), q, c->env_tails_on_acc ? q : c->s_b, c->env_b_tail_lanes ? (uint32_t)c->env_b_tail_lanes : tail_lanes));    // tcc:499-506
     ZK_HIP(hipEventRecord(c->ev_b1, c->s_b));
     if (!t->share_A) { ZK_TRY(c->mA.enqueue_sort(c->d_w, c->dA_idx, c->rA.n(), 0, m, k, ws)); ZK_TRY(release()); }
     ZK_HIP(hipEventRecord(c->ev_a0, q));
-    ZK_TRY(c->mA.enqueue_reduce(t->share_A ? c->mW.view_for(t->offA, t->posA) : c->mA.view(), q, c->s_a, tail_lanes));    // tcc:488-495
+    ZK_TRY(c->mA.enqueue_reduce(t->share_A ? c->mW.view_for(t->offA, t->posA) : c->mA.view(), q, c->env_tails_on_acc ? q : c->s_a, tail_lanes));    // tcc:488-495
     ZK_HIP(hipEventRecord(c->ev_a1, c->s_a));
     if (!t->share_L) { ZK_TRY(c->mL.enqueue_sort(c->d_w + (c->nIn + 1) + c->rL.lo, nullptr, c->rL.n(), 0, m, k, ws)); ZK_TRY(release()); }
     // One synchronous proof below ~2^19 constraints is a latency chain: folded into the H-query's reduction the L-query's pieces double the
@@ -1129,7 +1131,7 @@ static int prove_enqueue(zk_ctx *c, const uint64_t *witness, int canonical, int 
         ZK_TRY(c->mL.enqueue_accumulate(t->share_L ? c->mW.view_for(t->offL) : c->mL.view(), q));
         ZK_HIP(hipEventRecord(c->ev_l1, q));
     } else {
-        ZK_TRY(c->mL.enqueue_reduce(t->share_L ? c->mW.view_for(t->offL) : c->mL.view(), q, c->s_l, tail_lanes));
+        ZK_TRY(c->mL.enqueue_reduce(t->share_L ? c->mW.view_for(t->offL) : c->mL.view(), q, c->env_tails_on_acc ? q : c->s_l, tail_lanes));
         ZK_HIP(hipEventRecord(c->ev_l1, c->s_l));
     }
     }
@@ -1138,7 +1140,8 @@ static int prove_enqueue(zk_ctx *c, const uint64_t *witness, int canonical, int 
     else ZK_HIP(hipStreamWaitEvent(q, c->ev_sort_h, 0));
     ZK_TRY(c->mH.enqueue_accumulate(c->mH.view(), q));
     hipStream_t ts = hs;                                        // stream of the (merged) H tail
-    if (c->cur_merge && !c->serial && c->env_hl_tail) ts = c->env_hl_tail == 'l' ? c->s_l : c->env_hl_tail == 'a' ? c->s_a : hs;
+    if (c->env_tails_on_acc) ts = q;
+    else if (c->cur_merge && !c->serial && c->env_hl_tail) ts = c->env_hl_tail == 'l' ? c->s_l : c->env_hl_tail == 'a' ? c->s_a : hs;
     ZK_TRY(c->mH.enqueue_tail(ts, tail_lanes, c->cur_merge ? &c->mL : nullptr));     // one bucket reduction for Ht + Lt
     ZK_HIP(hipEventRecord(c->ev_h1, ts));
     return ZK_OK;
