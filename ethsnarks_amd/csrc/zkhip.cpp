@@ -678,12 +678,21 @@ void stream_park(hipStream_t st, int device, int role, int prio) {
 enum { ROLE_MAIN = 0, ROLE_ACC, ROLE_A, ROLE_B, ROLE_L, ROLE_COPY };
 }  // namespace
 
+// proofs in flight per device, over all contexts of the process: a proof that is queued while nothing else is in flight will (start to) run
+// alone on the machine, whichever entry point it came through, and takes the latency shapes of the bucket reductions (four lanes per point
+// operation, the whole workgroup per row: zk_prove's); proofs queued behind others are throughput work
+namespace { std::atomic<int> g_dev_inflight[64]; }
 struct zk_ctx {
     int device = 0;
     int stream_prio[6] = {0, 0, 0, 0, 0, 0};   // priority each role's stream was taken with (stream_park files it under the same key)
     DeviceTables *tables = nullptr;
     bool serial = false;
     bool in_flight = false;
+    bool alone_hint = false;                   // nothing else was in flight on this device when the proof was queued
+    void set_in_flight(bool on) {
+        if (on != in_flight && device >= 0 && device < 64) g_dev_inflight[device].fetch_add(on ? 1 : -1, std::memory_order_relaxed);
+        in_flight = on;
+    }
     bool awaiting_h = false;                   // the proof in flight was submitted without its H part (zk_prove_submit_defer_h): zk_prove_submit_h completes it
     uint32_t max_batch = 1, cur_batch = 1;     // proofs per launch sequence: capacity, and of the proof(s) in flight
     uint32_t nC = 0, nIn = 0, V = 0, m = 0, logm = 0;
@@ -725,6 +734,7 @@ struct zk_ctx {
     hipEvent_t ev_start = nullptr, ev_w = nullptr, ev_h = nullptr, ev_a0 = nullptr, ev_a1 = nullptr, ev_b0 = nullptr, ev_b1 = nullptr,
                ev_l0 = nullptr, ev_l1 = nullptr, ev_h1 = nullptr, ev_h0 = nullptr;
     ~zk_ctx() {
+        set_in_flight(false);
         DeviceScope on(device);
         void *dev[] = {d_w, d_a, d_t, d_partials};           // d_b, d_c live inside d_a's allocation
         for (void *p : dev) if (p) hipFree(p);
@@ -1047,10 +1057,10 @@ static int prove_submit_impl(zk_ctx *c, const uint64_t *witness, int canonical, 
     const int rc = prove_enqueue(c, witness, canonical, resident, d_h, phase);
     if (rc != ZK_OK) {      // part of the proof may be queued: drain it so that the next submit cannot overwrite buffers still in use
         drain(c);
-        c->in_flight = c->awaiting_h = false;
+        c->set_in_flight(false); c->awaiting_h = false;
         return rc;
     }
-    c->in_flight = true;
+    c->set_in_flight(true);
     c->awaiting_h = phase == PHASE_WITNESS;
     return ZK_OK;
 }
@@ -1065,7 +1075,8 @@ static int prove_enqueue(zk_ctx *c, const uint64_t *witness, int canonical, int 
     // a synchronous call (one proof, the caller waits) reduces its buckets with four lanes per point operation whatever the size:
     // 3.5x shorter tails for 4x the lanes (sync zk_prove at 2^18 3.98 -> 3.75 ms, at 2^20 13.2 -> 12.2 ms incl. the upload; pipelined
     // proofs of those sizes lose 6 % of throughput with it and keep one lane)
-    const uint32_t tail_lanes = c->latency_call ? 4 : 0;
+    if (phase != PHASE_H) c->alone_hint = c->device >= 0 && c->device < 64 && g_dev_inflight[c->device].load(std::memory_order_relaxed) == 0;
+    const uint32_t tail_lanes = (c->latency_call || c->alone_hint) ? 4 : 0;
     auto release = [&]() -> int { if (q != m) { ZK_HIP(hipEventRecord(c->ev_sort, m)); ZK_HIP(hipStreamWaitEvent(q, c->ev_sort, 0)); } return ZK_OK; };
     // the H pipeline: on s_main behind the witness sorts, or -- split -- on its own stream beside them (it only needs the upload);
     // its launches are queued right after the first sort, ahead of the reductions' (the host enqueues ~5 us per launch)
@@ -1152,7 +1163,7 @@ static int prove_collect_impl(zk_ctx *c, zk_partials *out, zk_timings *tm) {    
     if (!c->in_flight) return fail(ZK_ERR_ARG, "no proof in flight on this context");
     if (c->awaiting_h) return fail(ZK_ERR_ARG, "the proof in flight has no H part yet (zk_prove_submit_h, or zk_prove_abort to drop it)");
     ZK_TRY(use_device(c->device));
-    c->in_flight = false;
+    c->set_in_flight(false);
     ZK_HIP(hipStreamSynchronize(c->s_acc)); ZK_HIP(hipStreamSynchronize(c->s_a)); ZK_HIP(hipStreamSynchronize(c->s_b));
     ZK_HIP(hipStreamSynchronize(c->s_l)); ZK_HIP(hipStreamSynchronize(c->s_h)); ZK_HIP(hipStreamSynchronize(c->s_main));
     for (uint32_t p = 0; p < c->cur_batch; p++)
@@ -1304,7 +1315,7 @@ extern "C" int zk_prove_abort(zk_ctx *c) try {
     if (!c) return fail(ZK_ERR_ARG, "null argument");
     ZK_TRY(use_device(c->device));
     drain(c);
-    c->in_flight = c->awaiting_h = false;
+    c->set_in_flight(false); c->awaiting_h = false;
     return ZK_OK;
 } ZK_GUARD
 
