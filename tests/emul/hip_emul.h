@@ -71,7 +71,10 @@ inline Fiber *g_cur = nullptr;
 inline std::function<void()> *g_body = nullptr;
 inline std::vector<Fiber> g_fibers;
 inline std::vector<char> g_stacks;
-constexpr size_t FIBER_STACK = 256 * 1024;
+#ifndef ZK_EMUL_FIBER_STACK
+#define ZK_EMUL_FIBER_STACK (256 * 1024)      // (a sanitizer build inflates the kernels' frames: build it with a larger value)
+#endif
+constexpr size_t FIBER_STACK = ZK_EMUL_FIBER_STACK;
 #if defined(__x86_64__)
 inline void yield_to_scheduler() { zk_emul_switch(&g_cur->sp, g_sched_sp); }
 inline void trampoline() { (*g_body)(); g_cur->done = true; yield_to_scheduler(); __builtin_trap(); }
