@@ -396,6 +396,7 @@ def main():
                                    "measured on MI355X the kernel's time is the SUM of its instructions' issue times (multiplies ~5.9 cycles, carry adds ~2.4: "
                                    "tools/mulbench.cpp, DESIGN section 4), so the multiplies alone cap it at ~0.65 of this peak" % (devinfo["compute_units"], devinfo["clock_mhz"] / 1e3),
                      "mads_per_mixed_addition": MADS_PER_G2_MADD},
+            "valu_issue": valu_issue(args.workload, logm, world if shard else 1, 1e3 * elapsed / args.steps / max(1, kb), devinfo),
             "proof_hbm": {"algorithmic_bytes_per_proof": bytes_per_proof,
                           "achieved_GBps": round(bytes_per_proof * value / 1e9, 3),
                           "frac_of_peak": round(bytes_per_proof * value / 1e9 / (world * HBM_PEAK_GBPS), 6)},
@@ -462,6 +463,25 @@ def pmc_traffic(kernel, workload, logm, shards):
             PMC_PROFILE, cfg.get("workload"), cfg.get("logm"), cfg.get("shards", 1))
     except Exception:
         return None, "no PMC profile committed"
+
+
+def valu_issue(workload, logm, shards, ms_per_proof, devinfo):
+    """The whole step against the VALU-issue bound of the instructions it executes: wave-level VALU instructions per proof from the committed SQ-counter
+    pass of THESE kernels (profiles/r04_instruction_counts.json <- r04_sq_counters.txt; quoted only while the kernel sources match), the issue time of
+    their mix (v_mad_u64_u32 5.9 cycles, everything else 2.4: measured), and the SIMD-cycles the timed steps really took per proof."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r04_instruction_counts.json")))
+        cfg = d.get("config", {})
+        if d.get("kernel_sources_sha16") != kernel_sources_sha16() or cfg.get("workload") != workload or cfg.get("logm") != logm or cfg.get("shards", 1) != shards:
+            return None
+        insts, bound_cpi = d["wave_valu_instructions_per_proof"], d["issue_bound_cycles_per_instruction"]
+        simd_cycles = ms_per_proof * 1e-3 * devinfo["clock_mhz"] * 1e6 * devinfo["compute_units"] * 4
+        return {"wave_valu_instructions_per_proof": insts, "cycles_per_instruction": round(simd_cycles / insts, 3), "issue_bound_cycles_per_instruction": bound_cpi,
+                "frac": round(bound_cpi * insts / simd_cycles, 4), "source": "profiles/r04_instruction_counts.json (commit %s)" % d.get("commit", "?"),
+                "note": "the step is its instruction count: SIMD-cycles per wave-level VALU instruction of the timed steps against the issue time of the instruction mix "
+                        "(no schedule, priority or occupancy change moves the step any more: profiles/r04_schedule_sweep.txt)"}
+    except Exception:
+        return None
 
 
 def proof_bytes(r1cs, pk, m):
